@@ -1,0 +1,173 @@
+/*
+ * svamd.h - C ABI of libsvamd.so, the MI355X (gfx950) implementation of the
+ * normalised cross-correlation hot path of jessefr0st999/stereo-vision.
+ *
+ * The reference is pure Python and has no FFI of its own; each entry point
+ * below replaces the Python function cited beside it (paths relative to the
+ * reference checkout) and is what a ctypes binding in that function's module
+ * would call.  The binding stubs are shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - Every array argument is a DEVICE pointer (hipMalloc'd or a torch tensor's
+ *    data_ptr()) unless its comment says "host".  Nothing is allocated or freed
+ *    by the library: callers pass outputs and, where a function needs scratch
+ *    memory, a workspace of at least <fn>_workspace_bytes(...) bytes, 256-byte
+ *    aligned.
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Calls
+ *    only enqueue work; they do not synchronise.
+ *  - Images and templates are row-major; sizes are in elements.
+ *  - Return value: SVAMD_OK or an SVAMD_ERR_* code; svamd_last_error() returns
+ *    a message for the calling thread's most recent failure.
+ */
+#ifndef SVAMD_H
+#define SVAMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVAMD_OK             0
+#define SVAMD_ERR_INVALID    1   /* bad argument (NULL, non-positive size, unsupported dtype) */
+#define SVAMD_ERR_SHAPE      2   /* shape rule of the reference violated (it raises Exception) */
+#define SVAMD_ERR_WORKSPACE  3   /* workspace missing, too small or misaligned */
+#define SVAMD_ERR_HIP        4   /* HIP runtime error */
+#define SVAMD_ERR_LIMIT      5   /* size beyond what the kernel supports */
+
+/* element types of image arguments */
+#define SVAMD_U8   0
+#define SVAMD_F32  1
+#define SVAMD_F64  2
+
+/* precision of the multiply-accumulate in svamd_scan_pairs */
+#define SVAMD_ACC_F32 0
+#define SVAMD_ACC_F64 1
+
+/* selection rule of svamd_band_scan_u8 */
+#define SVAMD_BAND_ARGMAX 0     /* first maximum in ascending offset (utils.py:17-26) */
+#define SVAMD_BAND_FOLD   1     /* image_scan's rule (sv_image_comparison.py:249-255) */
+
+#define SVAMD_BAND_NO_MATCH INT32_MIN
+
+/* flags of svamd_band_scan_u8 */
+#define SVAMD_BAND_PREPARED 1   /* the workspace already holds svamd_band_prepare_u8's tables */
+
+int svamd_version(void);
+const char *svamd_last_error(void);
+
+/* ---- K1: summed-area tables -------------------------------------------------
+ * No counterpart function in the reference: replaces the per-output
+ * region_snapshot.mean() / .std() of correlation.py:106,112.
+ * s1, s2: (h+1) x (w+1) tables of sum(v - offset) and sum((v - offset)^2) with a
+ * zero first row and column.  U8 input -> int64 tables (exact); F32/F64 input
+ * -> double tables. */
+int svamd_sat2d(const void *img, int dtype, int h, int w, int64_t pitch,
+                double offset, void *s1, void *s2, void *stream);
+
+/* ---- a11: utils.max_pos(array, step_x, step_y) ---------------------------------
+ * utils.py:17-26: index of the first maximum ignoring NaNs (numpy.nanargmax);
+ * *out_index = -1 when every element is NaN (numpy raises ValueError there).
+ * The (x, y) scaling by the steps is left to the caller. */
+int svamd_nanargmax(const double *data, int64_t n, int64_t *out_index, void *stream);
+
+/* ---- a1: cross_correlate_2d(template, region, step_x, step_y) ----------------
+ * correlation.py:77-117.  tmpl: th x tw float64, NaN = masked pixel.  region:
+ * rh x rw of `region_dtype`.  out: ceil(rh/step_y) x ceil(rw/step_x) float64.
+ * SVAMD_ERR_SHAPE when the template exceeds the region (correlation.py:81-82). */
+size_t svamd_cross_correlate_2d_workspace_bytes(int th, int tw, int rh, int rw);
+int svamd_cross_correlate_2d(const double *tmpl, int th, int tw,
+                             const void *region, int region_dtype, int rh, int rw,
+                             int step_x, int step_y, double *out,
+                             void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- a2: cross_correlate_2d_spectral(template, region) ------------------------
+ * correlation_spectral.py:32-55.  out: rh x rw float64 (the circular,
+ * globally normalised surface).  min_std / min_mean_diff are the module
+ * constants MIN_ST_DEV / MIN_MEAN_DIFF (correlation_spectral.py:6,10). */
+size_t svamd_cross_correlate_2d_spectral_workspace_bytes(int th, int tw, int rh, int rw);
+int svamd_cross_correlate_2d_spectral(const void *tmpl, int tmpl_dtype, int th, int tw,
+                                      const void *region, int region_dtype, int rh, int rw,
+                                      double min_std, double min_mean_diff, double *out,
+                                      void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- a3: cross_correlate_1d(vec_1, vec_2, normalised) -------------------------
+ * correlation.py:44-75 (and its list twin cross_correlate_1d_raw, :4-42).
+ * v1, v2: n float64.  out: 2n-1 float64. */
+size_t svamd_cross_correlate_1d_workspace_bytes(int64_t n);
+int svamd_cross_correlate_1d(const double *v1, const double *v2, int64_t n, int normalised,
+                             double *out, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- a5: cross_correlate_1d_spectral(template, signal) ------------------------
+ * correlation_spectral.py:12-30.  out: ns + nt - 1 float64. */
+size_t svamd_cross_correlate_1d_spectral_workspace_bytes(int64_t nt, int64_t ns);
+int svamd_cross_correlate_1d_spectral(const double *tmpl, int64_t nt, const double *signal, int64_t ns,
+                                      double *out, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- a6 inner loop: x_corr_2d + np.max over many (template, region) pairs ------
+ * sv_image_comparison.py:243-244 for every pair of a scan at once.
+ * tbase / rbase: float64 arrays (the left / right image, or one packed buffer).
+ * desc: npairs x 8 int64 = {t_off, t_pitch, t_h, t_w, r_off, r_pitch, r_h, r_w},
+ * offsets and pitches in elements.  max_side: an upper bound of every t_h, t_w,
+ * r_h, r_w of the call, at most SVAMD_PAIR_MAX_SIDE (it sizes the LDS tile; a
+ * pair that exceeds it yields NaN).
+ * out_max[p]: numpy.max of the pair's surface (NaN-propagating); pairs with an
+ * empty region give NaN.  out_argmax (nullable): numpy.nanargmax of the surface
+ * (-1 if all NaN).  surfaces (nullable): the r_h x r_w surfaces back to back in
+ * pair order, starting at surf_off[p] (int64 element offsets). */
+#define SVAMD_PAIR_MAX_SIDE 64
+int svamd_scan_pairs(const double *tbase, const double *rbase,
+                     const int64_t *desc, int64_t npairs, int max_side,
+                     double min_std, double min_mean_diff, int acc_precision,
+                     double *out_max, int64_t *out_argmax,
+                     double *surfaces, const int64_t *surf_off, void *stream);
+
+/* ---- a6 selection rule ---------------------------------------------------------
+ * sv_image_comparison.py:236-255 for every window at once.  win_off: nwin+1
+ * int64 offsets into the pair arrays (regions of one window are contiguous and
+ * in the reference's visiting order); is_centre[p] != 0 where the region's
+ * centre equals the window's; skip[p] != 0 for empty regions (:241-242).
+ * best_pair[w]: winning pair index or -1; best_val[w]: its correlation or 0.
+ * min_margin (nullable): per window, the smallest distance of any comparison
+ * the rule made from flipping (used to re-check float32 decisions in float64). */
+int svamd_scan_fold(const double *corr_max, const uint8_t *is_centre, const uint8_t *skip,
+                    const int64_t *win_off, int64_t nwin, double threshold, double centre_tol,
+                    int64_t *best_pair, double *best_val, double *min_margin, void *stream);
+
+/* ---- dense band scan ------------------------------------------------------------
+ * For every win_w x win_h window of the left image (origins on a stride grid,
+ * windows fully inside the image) and every horizontal offset d in
+ * [-max_disp, +max_disp] whose box lies inside the right image, the spatial NCC
+ * of correlation.py:104-116 at full overlap, i.e. row 0 of
+ * cross_correlate_2d(window, band); then per window either utils.max_pos's
+ * arg-max (utils.py:17-26) or image_scan's selection rule
+ * (sv_image_comparison.py:249-255, centre offset first, then ascending d).
+ * left, right: H x W uint8.  Windows: nwy x nwx = ((H-win_h)/stride_y+1) x
+ * ((W-win_w)/stride_x+1).  out_disp: int32 (SVAMD_BAND_NO_MATCH when arg-max
+ * found no finite score; 0 when the rule selected nothing).  out_val: float64.
+ * scores (nullable): nwy x nwx x (2*max_disp+1) float64, NaN where invalid.
+ * Rows [row_begin, row_end) of the window grid are processed (for sharding
+ * over devices); outputs are indexed by absolute window row.
+ * flags: 0, or SVAMD_BAND_PREPARED when svamd_band_prepare_u8 has already run on
+ * these images into this workspace (e.g. one prepare, then one scan per row
+ * shard).  Limits: win_w * win_h <= 1024 (exact float32 accumulation);
+ * stride_x == 1; win_w one of the widths the kernel is compiled for. */
+size_t svamd_band_scan_u8_workspace_bytes(int H, int W, int win_w, int win_h);
+
+/* K1 for the band scan: summed-area tables of both images and, from them, the
+ * per-position window sums and inverse deviations, into the workspace. */
+int svamd_band_prepare_u8(const uint8_t *left, const uint8_t *right, int H, int W,
+                          int win_w, int win_h, void *workspace, size_t workspace_bytes,
+                          void *stream);
+int svamd_band_scan_u8(const uint8_t *left, const uint8_t *right, int H, int W,
+                       int win_w, int win_h, int stride_x, int stride_y, int max_disp,
+                       int mode, double threshold, double centre_tol,
+                       int row_begin, int row_end, int flags,
+                       int32_t *out_disp, double *out_val, double *scores,
+                       void *workspace, size_t workspace_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVAMD_H */

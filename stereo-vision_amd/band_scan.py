@@ -1,0 +1,103 @@
+'''Dense horizontal-band stereo scan on MI355X.
+
+The reference scans a stereo pair by calling its correlator once per (window,
+candidate region) pair from Python.  For the dense case - a window at every
+pixel and a band of candidate offsets on the same image rows - libsvamd
+evaluates all of it in one kernel (svamd_band_scan_u8): the spatial NCC of
+reference correlation.py:104-116 at full overlap, then per window either the
+arg-max of utils.max_pos (utils.py:17-26) or image_scan's selection rule
+(sv_image_comparison.py:249-255).
+'''
+import numpy as np
+
+import _native as nv
+import sv_image_comparison as _svic
+
+WINDOW_WIDTHS = (7, 11, 15, 21, 31)    # widths the tuned kernel is compiled for
+
+
+def as_uint8_image(image):
+    '''uint8 view of an image given either as uint8 or as uint8 / 255 floats (what
+    the stereo driver feeds sequence_scan); anything else is rejected, because
+    the band kernel's exactness rests on 8-bit integer pixels.'''
+    image = np.asarray(image)
+    if image.dtype == np.uint8:
+        return np.ascontiguousarray(image)
+    if image.dtype.kind == 'f':
+        q = np.rint(image * 255.0)
+        if q.min() >= 0 and q.max() <= 255 and np.array_equal(q / 255.0, image):
+            return np.ascontiguousarray(q.astype(np.uint8))
+    raise TypeError('band_scan needs 8-bit images (uint8, or uint8 / 255 as float)')
+
+
+class BandScanner:
+    '''Device-resident state for repeated scans of same-sized pairs: images,
+    workspace and outputs are allocated once.'''
+
+    def __init__(self, height, width, window_width, window_height, max_disparity, row_stride=1,
+                 want_scores=False):
+        torch = nv.torch_cuda()
+        lib = nv.load_library()
+        self.shape = (height, width)
+        self.win = (window_width, window_height)
+        self.max_disp = int(max_disparity)
+        self.row_stride = int(row_stride)
+        self.nwx = width - window_width + 1
+        self.nwy = (height - window_height) // self.row_stride + 1
+        if self.nwx <= 0 or self.nwy <= 0:
+            raise Exception('Dimensions of template must not exceed those of region.')
+        nbytes = lib.svamd_band_scan_u8_workspace_bytes(height, width, window_width, window_height)
+        self.ws = nv.workspace(nbytes)
+        self.left = nv.empty((height, width), torch.uint8)
+        self.right = nv.empty((height, width), torch.uint8)
+        self.disp = nv.empty((self.nwy, self.nwx), torch.int32)
+        self.val = nv.empty((self.nwy, self.nwx), torch.float64)
+        self.scores = (nv.empty((self.nwy, self.nwx, 2 * self.max_disp + 1), torch.float64)
+                       if want_scores else None)
+
+    def upload(self, left, right):
+        torch = nv.torch_cuda()
+        self.left.copy_(torch.from_numpy(as_uint8_image(left)))
+        self.right.copy_(torch.from_numpy(as_uint8_image(right)))
+
+    def prepare(self):
+        '''Enqueues the summed-area tables / window statistics of the uploaded
+        pair (kernel K1); run(prepared=True) then skips them.'''
+        h, w = self.shape
+        nv.call('svamd_band_prepare_u8', nv.ptr(self.left), nv.ptr(self.right), h, w,
+                self.win[0], self.win[1], nv.ptr(self.ws), self.ws.numel(), nv.stream_ptr())
+
+    def run(self, correlation_threshold=None, rows=None, prepared=False):
+        '''Enqueues one scan on the current stream.  correlation_threshold None:
+        plain arg-max per window; a number: image_scan's selection rule with that
+        threshold and the module's CENTRE_TOL.  rows: (begin, end) window rows.'''
+        h, w = self.shape
+        mode = nv.BAND_ARGMAX if correlation_threshold is None else nv.BAND_FOLD
+        begin, end = rows if rows is not None else (0, self.nwy)
+        nv.call('svamd_band_scan_u8', nv.ptr(self.left), nv.ptr(self.right), h, w,
+                self.win[0], self.win[1], 1, self.row_stride, self.max_disp, mode,
+                float(correlation_threshold or 0.0), float(_svic.CENTRE_TOL), int(begin), int(end),
+                nv.BAND_PREPARED if prepared else 0,
+                nv.ptr(self.disp), nv.ptr(self.val), nv.ptr(self.scores),
+                nv.ptr(self.ws), self.ws.numel(), nv.stream_ptr())
+
+
+def band_scan(left_image, right_image, window_width, window_height, max_disparity,
+              correlation_threshold=None, row_stride=1, want_scores=False):
+    '''Scans every window_width x window_height window of the left image against
+    the right image at horizontal offsets -max_disparity..+max_disparity.
+    Returns (disparity int32 [rows, cols], correlation float64 [rows, cols]) and,
+    if asked, the full score volume [rows, cols, 2*max_disparity+1] (NaN where a
+    candidate box leaves the image or a window is constant).'''
+    left = as_uint8_image(left_image)
+    right = as_uint8_image(right_image)
+    if left.shape != right.shape:
+        raise Exception('Dimensions of template and region images must match')
+    scanner = BandScanner(left.shape[0], left.shape[1], window_width, window_height, max_disparity,
+                          row_stride, want_scores)
+    scanner.upload(left, right)
+    scanner.run(correlation_threshold)
+    out = (scanner.disp.cpu().numpy(), scanner.val.cpu().numpy())
+    if want_scores:
+        out += (scanner.scores.cpu().numpy(),)
+    return out

@@ -1,0 +1,469 @@
+// Dense band scan: zero-mean normalised cross-correlation of every win_w x win_h
+// window of the left image against the same-row boxes of the right image at all
+// horizontal offsets d in [-max_disp, +max_disp], with the per-window arg-max or
+// selection rule fused in.
+//
+// Arithmetic.  With l = L - 128 and r = R - 128 (integers in [-128, 127]) and
+// n = win_w * win_h <= 1024, every partial sum of sum(l * r) is an integer of
+// magnitude < 2^24, so the float32 fused multiply-adds below are EXACT.  The
+// score is then formed in float64 from exact integers,
+//     ncc = (n * sum(l r) - sum(l) sum(r)) / sqrt(A_L * A_R),  A = n sum(x^2) - sum(x)^2,
+// where sum(l), sum(r), A_L, A_R come from summed-area tables (kernel K1) through
+// a per-position table of window sums and 1/sqrt(A).
+//
+// Mapping.  A workgroup is 16 wavefronts and owns a tile of 16 window rows x 256
+// window columns.  Its left tile and the matching band of the right image are
+// staged once in LDS as float32.  Wavefront w owns window row w; lane i owns the
+// 4 consecutive windows 4i..4i+3 and, per pass, 8 consecutive offsets: 32
+// accumulators per lane.  For each image row the lane walks the 34 columns its 4
+// windows span: one ds_read_b128 per 4 left pixels, one per 4 new right pixels,
+// up to 128 FMAs in between (about 50 FMAs per LDS read instruction), so the
+// loop is bound by the vector ALU, not by LDS.  Offsets are visited in ascending
+// order inside a lane, so the sequential selection rule needs no cross-lane
+// traffic at all; only the final results are written.
+#include "common.h"
+#include "kernels.h"
+
+namespace svamd {
+
+constexpr int BAND_X = 4;                 // windows per lane
+constexpr int BAND_D = 8;                 // offsets per pass
+constexpr int BAND_TX = WAVE * BAND_X;    // window columns per tile
+constexpr int BAND_WAVES = 16;            // window rows per tile
+constexpr int BAND_THREADS = BAND_WAVES * WAVE;
+constexpr int BAND_LDS_LIMIT = 160 * 1024;
+
+struct BandGeom {
+    int H, W, win_w, win_h, stride_y, max_disp, nd;
+    int nwx, nwy, nsx;        // window grid; nsx = W - win_w + 1 = columns of the stats tables
+    int mode;
+    double thr, tol;
+    int row_begin, row_end;
+    int lpitch, rpitch, tile_rows, dchunk;
+    int tile_wrows;           // window rows per tile (<= BAND_WAVES; fewer when rows are strided)
+};
+
+// ---- per-position window statistics from the summed-area tables -----------------
+__global__ void __launch_bounds__(256)
+window_stats_kernel(const uint32_t *__restrict__ s1, const uint32_t *__restrict__ s2, int H, int W, int win_w,
+                    int win_h, int32_t *__restrict__ wsum, double *__restrict__ winv)
+{
+    const int nsx = W - win_w + 1, nsy = H - win_h + 1;
+    const int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)nsx * nsy)
+        return;
+    const int y = (int)(idx / nsx), x = (int)(idx - (int64_t)y * nsx);
+    const int64_t tp = (int64_t)W + 1;
+    const int64_t a = (int64_t)y * tp + x, b = (int64_t)(y + win_h) * tp + x;
+    // unsigned wrap-around differences: exact because the true sums fit 32 bits
+    const uint32_t d1 = s1[b + win_w] - s1[a + win_w] - s1[b] + s1[a];
+    const uint32_t d2 = s2[b + win_w] - s2[a + win_w] - s2[b] + s2[a];
+    const int64_t sum = (int32_t)d1;
+    const int64_t n = (int64_t)win_w * win_h;
+    const int64_t A = n * (int64_t)d2 - sum * sum;
+    wsum[idx] = (int32_t)sum;
+    winv[idx] = A > 0 ? 1.0 / sqrt((double)A) : NAN;  // constant window: std == 0 -> NaN score
+}
+
+// ---- LDS tile staging ---------------------------------------------------------------
+// dst[r][c] = img[row0 + r][col0 + c] - 128 as float32, 0 outside the image.
+__device__ __forceinline__ void stage_tile(const uint8_t *__restrict__ img, int H, int W, int row0,
+                                           int nrows, int col0, int pitch, float *__restrict__ dst)
+{
+    const int quads = pitch / 4;
+    for (int i = threadIdx.x; i < nrows * quads; i += BAND_THREADS) {
+        const int r = i / quads, q = i - r * quads;
+        const int y = row0 + r, x = col0 + 4 * q;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (y >= 0 && y < H) {
+            const uint8_t *src = img + (int64_t)y * W;
+            if (x >= 0 && x + 0 < W) v.x = (float)src[x + 0] - 128.f;
+            if (x + 1 >= 0 && x + 1 < W) v.y = (float)src[x + 1] - 128.f;
+            if (x + 2 >= 0 && x + 2 < W) v.z = (float)src[x + 2] - 128.f;
+            if (x + 3 >= 0 && x + 3 < W) v.w = (float)src[x + 3] - 128.f;
+        }
+        *reinterpret_cast<float4 *>(dst + r * pitch + 4 * q) = v;
+    }
+}
+
+template <bool ALIGNED>
+__device__ __forceinline__ void load4(float *dst, const float *src)
+{
+    if constexpr (ALIGNED) {
+        const float4 v = *reinterpret_cast<const float4 *>(src);
+        dst[0] = v.x;
+        dst[1] = v.y;
+        dst[2] = v.z;
+        dst[3] = v.w;
+    } else {
+        dst[0] = src[0];
+        dst[1] = src[1];
+        dst[2] = src[2];
+        dst[3] = src[3];
+    }
+}
+
+// acc[x][d] += sum over `rows` image rows and the window's columns of
+//              L[row][x + b] * R[row][x + b + d],  b < WIN_W
+// lp / rp point at the lane's first left column / first right column (offset d = 0
+// of this pass) in the first row.
+template <int WIN_W, int D, bool ALIGNED>
+__device__ __forceinline__ void accumulate(const float *__restrict__ lp, const float *__restrict__ rp,
+                                           int lpitch, int rpitch, int rows, float (&acc)[BAND_X][D])
+{
+    constexpr int NU = WIN_W + BAND_X - 1;       // left columns touched by the lane's windows
+    constexpr int NCL = (NU + 3) / 4;            // ... in groups of four
+    constexpr int NCR = (NU + D - 1 + 3) / 4;    // right columns in groups of four
+    constexpr int AHEAD = (D + 2) / 4;           // right groups needed beyond group c
+#pragma unroll 1
+    for (int a = 0; a < rows; ++a) {
+        float rv[NCR * 4];
+#pragma unroll
+        for (int c = 0; c < AHEAD && c < NCR; ++c)
+            load4<ALIGNED>(rv + 4 * c, rp + 4 * c);
+#pragma unroll
+        for (int c = 0; c < NCL; ++c) {
+            float lv[4];
+            load4<true>(lv, lp + 4 * c);
+            if (c + AHEAD < NCR)
+                load4<ALIGNED>(rv + 4 * (c + AHEAD), rp + 4 * (c + AHEAD));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int u = 4 * c + i;
+                if (u < NU) {
+#pragma unroll
+                    for (int x = 0; x < BAND_X; ++x) {
+                        if (x <= u && u < x + WIN_W) {
+#pragma unroll
+                            for (int d = 0; d < D; ++d)
+                                acc[x][d] = fmaf(lv[i], rv[u + d], acc[x][d]);
+                        }
+                    }
+                }
+            }
+        }
+        lp += lpitch;
+        rp += rpitch;
+    }
+}
+
+struct LaneState {
+    double s1l[BAND_X];    // sum of (L - 128) over the window
+    double invl[BAND_X];   // 1 / sqrt(A_L)
+    double best[BAND_X];
+    int arg[BAND_X];
+};
+
+// Turns the D accumulators of each window into scores and feeds the selection.
+// k0: offset index (0 .. nd-1) of acc[.][0]; centre_pass: this pass evaluates the
+// centre offset ahead of the ascending sweep (selection-rule mode only).
+template <int D>
+__device__ __forceinline__ void finish_pass(const BandGeom &g, const float (&acc)[BAND_X][D], int k0,
+                                            int kend, bool centre_pass, int wy, int xbase,
+                                            const int32_t *__restrict__ wsum_r,
+                                            const double *__restrict__ winv_r, LaneState &st,
+                                            double *__restrict__ scores)
+{
+    const double n = (double)(g.win_w * g.win_h);
+    const int64_t srow = (int64_t)wy * g.stride_y * g.nsx;
+#pragma unroll
+    for (int x = 0; x < BAND_X; ++x) {
+        const int xw = xbase + x;
+        const bool wvalid = xw < g.nwx;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int k = k0 + d;
+            const int xr = xw + k - g.max_disp;
+            const bool kvalid = k < kend;
+            const bool valid = wvalid && kvalid && xr >= 0 && xr < g.nsx;
+            double s = NAN;
+            if (valid) {
+                const double s1r = (double)wsum_r[srow + xr];
+                const double num = fma(n, (double)acc[x][d], -(st.s1l[x] * s1r));
+                s = num * st.invl[x] * winv_r[srow + xr];
+            }
+            if (scores && wvalid && kvalid)
+                scores[((int64_t)wy * g.nwx + xw) * g.nd + k] = s;
+            if (!kvalid)
+                continue;
+            if (g.mode == SVAMD_BAND_ARGMAX) {
+                if (s > st.best[x]) {
+                    st.best[x] = s;
+                    st.arg[x] = k - g.max_disp;
+                }
+            } else if (centre_pass) {
+                if (s > g.thr && s >= st.best[x]) {
+                    st.best[x] = s;
+                    st.arg[x] = 0;
+                }
+            } else if (k != g.max_disp) {
+                if (s > g.thr && s > st.best[x] + g.tol) {
+                    st.best[x] = s;
+                    st.arg[x] = k - g.max_disp;
+                }
+            }
+        }
+    }
+}
+
+template <int WIN_W>
+__global__ void __launch_bounds__(BAND_THREADS)
+band_scan_kernel(BandGeom g, const uint8_t *__restrict__ left, const uint8_t *__restrict__ right,
+                 const int32_t *__restrict__ wsum_l, const double *__restrict__ winv_l,
+                 const int32_t *__restrict__ wsum_r, const double *__restrict__ winv_r,
+                 int32_t *__restrict__ out_disp, double *__restrict__ out_val, double *__restrict__ scores)
+{
+    extern __shared__ __align__(16) float tile[];
+    float *Lt = tile;
+    float *Rt = tile + g.tile_rows * g.lpitch;
+
+    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+    const int x0 = blockIdx.x * BAND_TX;                      // first window column of the tile
+    const int wy0 = g.row_begin + blockIdx.y * g.tile_wrows;  // first window row of the tile
+    const int y0 = wy0 * g.stride_y;                          // first image row of the tile
+    const int wy = wy0 + wave;
+    const bool active = wave < g.tile_wrows && wy < g.row_end;  // wave-uniform
+    const int xbase = x0 + BAND_X * lane;
+    const int lrow = wave * g.stride_y;                       // tile row of this wave's first image row
+
+    LaneState st;
+#pragma unroll
+    for (int x = 0; x < BAND_X; ++x) {
+        const int xw = xbase + x;
+        const bool ok = active && xw < g.nwx;
+        const int64_t si = (int64_t)wy * g.stride_y * g.nsx + xw;
+        st.s1l[x] = ok ? (double)wsum_l[si] : 0.0;
+        st.invl[x] = ok ? winv_l[si] : NAN;
+        st.best[x] = g.mode == SVAMD_BAND_ARGMAX ? -INFINITY : 0.0;
+        st.arg[x] = g.mode == SVAMD_BAND_ARGMAX ? SVAMD_BAND_NO_MATCH : 0;
+    }
+
+    stage_tile(left, g.H, g.W, y0, g.tile_rows, x0, g.lpitch, Lt);
+    const float *lp = Lt + lrow * g.lpitch + BAND_X * lane;
+
+    if (g.mode == SVAMD_BAND_FOLD) {
+        // the centre offset is judged first: stage the right image at d = 0
+        stage_tile(right, g.H, g.W, y0, g.tile_rows, x0, g.lpitch, Rt);
+        __syncthreads();
+        if (active) {
+            float acc[BAND_X][1] = {};
+            accumulate<WIN_W, 1, true>(lp, Rt + lrow * g.lpitch + BAND_X * lane, g.lpitch, g.lpitch,
+                                       g.win_h, acc);
+            finish_pass<1>(g, acc, g.max_disp, g.nd, true, wy, xbase, wsum_r, winv_r, st, nullptr);
+        }
+    }
+
+    for (int k0 = 0; k0 < g.nd; k0 += g.dchunk) {
+        const int kend = min(k0 + g.dchunk, g.nd);
+        __syncthreads();  // previous contents of Rt are no longer read
+        stage_tile(right, g.H, g.W, y0, g.tile_rows, x0 - g.max_disp + k0, g.rpitch, Rt);
+        __syncthreads();
+        if (!active)
+            continue;
+        const float *rp = Rt + lrow * g.rpitch + BAND_X * lane;
+        int k = k0;
+        for (; k + BAND_D <= kend; k += BAND_D) {
+            float acc[BAND_X][BAND_D] = {};
+            accumulate<WIN_W, BAND_D, true>(lp, rp + (k - k0), g.lpitch, g.rpitch, g.win_h, acc);
+            finish_pass<BAND_D>(g, acc, k, kend, false, wy, xbase, wsum_r, winv_r, st, scores);
+        }
+        for (; k < kend; ++k) {  // fewer than 8 offsets left in this chunk
+            float acc[BAND_X][1] = {};
+            accumulate<WIN_W, 1, false>(lp, rp + (k - k0), g.lpitch, g.rpitch, g.win_h, acc);
+            finish_pass<1>(g, acc, k, kend, false, wy, xbase, wsum_r, winv_r, st, scores);
+        }
+    }
+
+    if (active) {
+#pragma unroll
+        for (int x = 0; x < BAND_X; ++x) {
+            const int xw = xbase + x;
+            if (xw < g.nwx) {
+                const int64_t o = (int64_t)wy * g.nwx + xw;
+                out_disp[o] = st.arg[x];
+                out_val[o] = (g.mode == SVAMD_BAND_ARGMAX && st.arg[x] == SVAMD_BAND_NO_MATCH) ? NAN
+                                                                                               : st.best[x];
+            }
+        }
+    }
+}
+
+struct BandWs {
+    size_t n_sat, n_stat;
+};
+static BandWs band_ws(int H, int W, int win_w, int win_h)
+{
+    BandWs b;
+    b.n_sat = (size_t)(H + 1) * (W + 1);
+    b.n_stat = (size_t)(H - win_h + 1) * (W - win_w + 1);
+    return b;
+}
+
+template <int WIN_W>
+static int band_launch(const BandGeom &g, size_t lds, dim3 grid, hipStream_t st, const uint8_t *left,
+                       const uint8_t *right, const int32_t *wl, const double *il, const int32_t *wr,
+                       const double *ir, int32_t *out_disp, double *out_val, double *scores)
+{
+    static bool raised = false;
+    if (!raised) {
+        SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&band_scan_kernel<WIN_W>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, BAND_LDS_LIMIT));
+        raised = true;
+    }
+    hipLaunchKernelGGL((band_scan_kernel<WIN_W>), grid, dim3(BAND_THREADS), lds, st, g, left, right, wl, il,
+                       wr, ir, out_disp, out_val, scores);
+    SV_LAUNCH_CHECK();
+    return SVAMD_OK;
+}
+
+}  // namespace svamd
+
+using namespace svamd;
+
+extern "C" size_t svamd_band_scan_u8_workspace_bytes(int H, int W, int win_w, int win_h)
+{
+    if (H <= 0 || W <= 0 || win_w <= 0 || win_h <= 0 || win_w > W || win_h > H)
+        return 0;
+    BandWs b = band_ws(H, W, win_w, win_h);
+    return 4 * align_up(b.n_sat * 4, 256) + 2 * align_up(b.n_stat * 4, 256) + 2 * align_up(b.n_stat * 8, 256);
+}
+
+namespace {
+struct BandTables {
+    uint32_t *s1l, *s2l, *s1r, *s2r;
+    int32_t *wl, *wr;
+    double *il, *ir;
+};
+BandTables band_tables(void *workspace, int H, int W, int win_w, int win_h)
+{
+    BandWs b = band_ws(H, W, win_w, win_h);
+    Carver ws(workspace);
+    BandTables t;
+    t.s1l = ws.take<uint32_t>(b.n_sat);
+    t.s2l = ws.take<uint32_t>(b.n_sat);
+    t.s1r = ws.take<uint32_t>(b.n_sat);
+    t.s2r = ws.take<uint32_t>(b.n_sat);
+    t.wl = ws.take<int32_t>(b.n_stat);
+    t.wr = ws.take<int32_t>(b.n_stat);
+    t.il = ws.take<double>(b.n_stat);
+    t.ir = ws.take<double>(b.n_stat);
+    return t;
+}
+}  // namespace
+
+extern "C" int svamd_band_prepare_u8(const uint8_t *left, const uint8_t *right, int H, int W, int win_w,
+                                     int win_h, void *workspace, size_t workspace_bytes, void *stream)
+{
+    SV_REQUIRE(left && right, SVAMD_ERR_INVALID, "band_prepare_u8: NULL pointer");
+    SV_REQUIRE(H > 0 && W > 0 && win_w > 0 && win_h > 0, SVAMD_ERR_INVALID, "band_prepare_u8: non-positive size");
+    SV_REQUIRE(win_w <= W && win_h <= H, SVAMD_ERR_SHAPE,
+               "Dimensions of template must not exceed those of region.");
+    SV_REQUIRE((int64_t)win_w * win_h <= 1024, SVAMD_ERR_LIMIT,
+               "band_prepare_u8: window area %d exceeds 1024", win_w * win_h);
+    SV_REQUIRE((int64_t)(H + 1) * (W + 1) < (1LL << 31), SVAMD_ERR_LIMIT, "band_prepare_u8: image too large");
+    SV_REQUIRE(workspace && (reinterpret_cast<uintptr_t>(workspace) & 255) == 0 &&
+                   workspace_bytes >= svamd_band_scan_u8_workspace_bytes(H, W, win_w, win_h),
+               SVAMD_ERR_WORKSPACE, "band_prepare_u8: workspace missing, misaligned or too small");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    BandWs b = band_ws(H, W, win_w, win_h);
+    BandTables t = band_tables(workspace, H, W, win_w, win_h);
+    int rc;
+    if ((rc = sat2d_launch<uint8_t, uint32_t>(left, H, W, W, 128u, t.s1l, t.s2l, st)) != SVAMD_OK) return rc;
+    if ((rc = sat2d_launch<uint8_t, uint32_t>(right, H, W, W, 128u, t.s1r, t.s2r, st)) != SVAMD_OK) return rc;
+    const unsigned sg = (unsigned)((b.n_stat + 255) / 256);
+    hipLaunchKernelGGL(window_stats_kernel, dim3(sg), dim3(256), 0, st, t.s1l, t.s2l, H, W, win_w, win_h,
+                       t.wl, t.il);
+    SV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(window_stats_kernel, dim3(sg), dim3(256), 0, st, t.s1r, t.s2r, H, W, win_w, win_h,
+                       t.wr, t.ir);
+    SV_LAUNCH_CHECK();
+    return SVAMD_OK;
+}
+
+extern "C" int svamd_band_scan_u8(const uint8_t *left, const uint8_t *right, int H, int W, int win_w,
+                                  int win_h, int stride_x, int stride_y, int max_disp, int mode,
+                                  double threshold, double centre_tol, int row_begin, int row_end,
+                                  int flags, int32_t *out_disp, double *out_val, double *scores,
+                                  void *workspace, size_t workspace_bytes, void *stream)
+{
+    SV_REQUIRE(left && right && out_disp && out_val, SVAMD_ERR_INVALID, "band_scan_u8: NULL pointer");
+    SV_REQUIRE(H > 0 && W > 0 && win_w > 0 && win_h > 0 && max_disp >= 0 && stride_y > 0, SVAMD_ERR_INVALID,
+               "band_scan_u8: non-positive size");
+    SV_REQUIRE(win_w <= W && win_h <= H, SVAMD_ERR_SHAPE,
+               "Dimensions of template must not exceed those of region.");
+    SV_REQUIRE(mode == SVAMD_BAND_ARGMAX || mode == SVAMD_BAND_FOLD, SVAMD_ERR_INVALID,
+               "band_scan_u8: unknown mode %d", mode);
+    SV_REQUIRE(stride_x == 1, SVAMD_ERR_LIMIT, "band_scan_u8: only stride_x == 1 is supported (got %d)",
+               stride_x);
+    SV_REQUIRE((int64_t)win_w * win_h <= 1024, SVAMD_ERR_LIMIT,
+               "band_scan_u8: window area %d exceeds 1024 (float32 accumulation would not be exact)",
+               win_w * win_h);
+    SV_REQUIRE((int64_t)(H + 1) * (W + 1) < (1LL << 31), SVAMD_ERR_LIMIT, "band_scan_u8: image too large");
+    SV_REQUIRE(workspace && (reinterpret_cast<uintptr_t>(workspace) & 255) == 0 &&
+                   workspace_bytes >= svamd_band_scan_u8_workspace_bytes(H, W, win_w, win_h),
+               SVAMD_ERR_WORKSPACE, "band_scan_u8: workspace missing, misaligned or too small");
+
+    BandGeom g;
+    g.H = H; g.W = W; g.win_w = win_w; g.win_h = win_h; g.stride_y = stride_y; g.max_disp = max_disp;
+    g.nd = 2 * max_disp + 1;
+    g.nwx = W - win_w + 1;
+    g.nwy = (H - win_h) / stride_y + 1;
+    g.nsx = W - win_w + 1;
+    g.mode = mode; g.thr = threshold; g.tol = centre_tol;
+    SV_REQUIRE(row_begin >= 0 && row_begin <= row_end && row_end <= g.nwy, SVAMD_ERR_INVALID,
+               "band_scan_u8: row range [%d, %d) outside 0..%d", row_begin, row_end, g.nwy);
+    g.row_begin = row_begin; g.row_end = row_end;
+    if (row_begin == row_end)
+        return SVAMD_OK;
+
+    // Tile geometry.  Row pitches carry 4 floats of slack because the last
+    // 4-wide LDS read of a lane may extend past the columns it uses.  As many
+    // offsets as fit in LDS are staged per pass over the right image.
+    g.lpitch = (int)align_up((size_t)(BAND_TX + win_w - 1), 4) + 4;
+    size_t lds = 0;
+    for (g.tile_wrows = BAND_WAVES; g.tile_wrows >= 1; --g.tile_wrows) {
+        g.tile_rows = (g.tile_wrows - 1) * stride_y + win_h;
+        g.dchunk = (int)align_up((size_t)g.nd, BAND_D);
+        for (;;) {
+            const int dcur = g.dchunk < g.nd ? g.dchunk : g.nd;
+            g.rpitch = (int)align_up((size_t)(BAND_TX + win_w - 1 + dcur - 1), 4) + 4;
+            if (g.rpitch < g.lpitch)
+                g.rpitch = g.lpitch;  // the centre pass stages a left-shaped tile into Rt
+            lds = (size_t)g.tile_rows * (g.lpitch + g.rpitch) * sizeof(float);
+            if (lds <= (size_t)BAND_LDS_LIMIT || g.dchunk <= BAND_D)
+                break;
+            g.dchunk -= BAND_D;
+        }
+        if (lds <= (size_t)BAND_LDS_LIMIT)
+            break;
+    }
+    SV_REQUIRE(lds <= (size_t)BAND_LDS_LIMIT, SVAMD_ERR_LIMIT,
+               "band_scan_u8: window %dx%d with row stride %d does not fit the LDS tile", win_w, win_h,
+               stride_y);
+
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (!(flags & SVAMD_BAND_PREPARED)) {
+        int rc = svamd_band_prepare_u8(left, right, H, W, win_w, win_h, workspace, workspace_bytes, stream);
+        if (rc != SVAMD_OK)
+            return rc;
+    }
+    BandTables t = band_tables(workspace, H, W, win_w, win_h);
+    const int32_t *wl = t.wl, *wr = t.wr;
+    const double *il = t.il, *ir = t.ir;
+
+    dim3 grid((g.nwx + BAND_TX - 1) / BAND_TX, (row_end - row_begin + g.tile_wrows - 1) / g.tile_wrows);
+#define SV_BAND_CASE(WW)                                                                          \
+    case WW:                                                                                      \
+        return band_launch<WW>(g, lds, grid, st, left, right, wl, il, wr, ir, out_disp, out_val, scores)
+    switch (win_w) {
+        SV_BAND_CASE(7);
+        SV_BAND_CASE(11);
+        SV_BAND_CASE(15);
+        SV_BAND_CASE(21);
+        SV_BAND_CASE(31);
+    default:
+        SV_REQUIRE(false, SVAMD_ERR_LIMIT,
+                   "band_scan_u8: window width %d has no compiled kernel (available: 7, 11, 15, 21, 31)", win_w);
+    }
+#undef SV_BAND_CASE
+}

@@ -1,0 +1,25 @@
+// Internal launch helpers shared between the translation units of libsvamd.
+#pragma once
+
+#include "common.h"
+
+namespace svamd {
+
+// sat.hip
+template <typename TIn, typename TAcc>
+int sat2d_launch(const TIn *img, int h, int w, int64_t pitch, TAcc offset, TAcc *s1, TAcc *s2,
+                 hipStream_t stream);
+
+// xcorr_slide.hip
+// Two-pass mean / population std of an h x w array (NaNs optionally ignored).
+int stats_launch(const void *src, int dtype, int h, int w, int64_t pitch, bool ignore_nan, Stats *out,
+                 hipStream_t stream);
+
+// Sliding dot product of a float32 template over a float32 image:
+//   out[i][j] = sum_{m<th, n<tw} t[m][n] * img[i*sy + m][j*sx + n]
+// for i < oh, j < ow; the image must cover every index touched.  Products are
+// accumulated in float32 over short runs and the runs in float64.
+int slide_launch(const float *t, int th, int tw, const float *img, int64_t img_pitch, int oh, int ow,
+                 int sx, int sy, double *out, hipStream_t stream);
+
+}  // namespace svamd

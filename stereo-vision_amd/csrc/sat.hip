@@ -1,0 +1,147 @@
+// K1: summed-area tables (integral images) by two prefix-scan passes.
+//
+// Pass 1 scans every image row with one 64-lane wavefront per row (shuffle-based
+// inclusive scan, 64 pixels per step, running carry in a register) and writes
+// the row prefix of v and v^2 into rows 1..h of the (h+1) x (w+1) tables.
+// Pass 2 scans the table columns in place, one thread per column, so that
+// neighbouring lanes touch neighbouring addresses (coalesced) at every row.
+// Integer inputs use integer accumulators, so window sums derived from the
+// tables are exact.  The unsigned 32-bit variant is allowed to wrap: a
+// rectangle sum taken as a 4-corner difference in unsigned arithmetic is exact
+// whenever the true sum fits in 32 bits.
+#include "common.h"
+#include "kernels.h"
+
+namespace svamd {
+
+template <typename TAcc>
+__device__ __forceinline__ TAcc wave_inclusive_scan(TAcc v, int lane)
+{
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1) {
+        TAcc n = __shfl_up(v, o, WAVE);
+        if (lane >= o)
+            v += n;
+    }
+    return v;
+}
+
+template <typename TIn, typename TAcc>
+__global__ void __launch_bounds__(256)
+sat_rows_kernel(const TIn *__restrict__ img, int h, int w, int64_t pitch, TAcc offset,
+                TAcc *__restrict__ s1, TAcc *__restrict__ s2)
+{
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int row = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
+    const int64_t tp = (int64_t)w + 1;
+    if (row > h)
+        return;
+    if (row == 0) {  // zero first table row
+        for (int x = lane; x <= w; x += WAVE) {
+            s1[x] = TAcc(0);
+            s2[x] = TAcc(0);
+        }
+        return;
+    }
+    const TIn *src = img + (int64_t)(row - 1) * pitch;
+    TAcc *d1 = s1 + (int64_t)row * tp;
+    TAcc *d2 = s2 + (int64_t)row * tp;
+    if (lane == 0) {
+        d1[0] = TAcc(0);
+        d2[0] = TAcc(0);
+    }
+    TAcc c1 = TAcc(0), c2 = TAcc(0);
+    for (int x0 = 0; x0 < w; x0 += WAVE) {
+        int x = x0 + lane;
+        TAcc v = x < w ? (TAcc)src[x] - offset : TAcc(0);
+        TAcc p1 = wave_inclusive_scan<TAcc>(v, lane) + c1;
+        TAcc p2 = wave_inclusive_scan<TAcc>(v * v, lane) + c2;
+        if (x < w) {
+            d1[x + 1] = p1;
+            d2[x + 1] = p2;
+        }
+        c1 = __shfl(p1, WAVE - 1, WAVE);
+        c2 = __shfl(p2, WAVE - 1, WAVE);
+    }
+}
+
+template <typename TAcc>
+__global__ void __launch_bounds__(256)
+sat_cols_kernel(int h, int w, TAcc *__restrict__ s1, TAcc *__restrict__ s2)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t tp = (int64_t)w + 1;
+    if (x > w)
+        return;
+    TAcc *t = blockIdx.y == 0 ? s1 : s2;
+    TAcc run = TAcc(0);
+    int y = 1;
+    for (; y + 8 <= h + 1; y += 8) {
+        TAcc v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            v[k] = t[(int64_t)(y + k) * tp + x];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            run += v[k];
+            t[(int64_t)(y + k) * tp + x] = run;
+        }
+    }
+    for (; y <= h; ++y) {
+        run += t[(int64_t)y * tp + x];
+        t[(int64_t)y * tp + x] = run;
+    }
+}
+
+template <typename TIn, typename TAcc>
+int sat2d_launch(const TIn *img, int h, int w, int64_t pitch, TAcc offset, TAcc *s1, TAcc *s2,
+                 hipStream_t stream)
+{
+    const int waves_per_block = 4;
+    dim3 g1((h + 1 + waves_per_block - 1) / waves_per_block);
+    hipLaunchKernelGGL((sat_rows_kernel<TIn, TAcc>), g1, dim3(waves_per_block * WAVE), 0, stream,
+                       img, h, w, pitch, offset, s1, s2);
+    SV_LAUNCH_CHECK();
+    dim3 g2((w + 1 + 255) / 256, 2);
+    hipLaunchKernelGGL((sat_cols_kernel<TAcc>), g2, dim3(256), 0, stream, h, w, s1, s2);
+    SV_LAUNCH_CHECK();
+    return SVAMD_OK;
+}
+
+template int sat2d_launch<uint8_t, uint32_t>(const uint8_t *, int, int, int64_t, uint32_t, uint32_t *,
+                                             uint32_t *, hipStream_t);
+template int sat2d_launch<uint8_t, int64_t>(const uint8_t *, int, int, int64_t, int64_t, int64_t *,
+                                            int64_t *, hipStream_t);
+template int sat2d_launch<float, double>(const float *, int, int, int64_t, double, double *, double *,
+                                         hipStream_t);
+template int sat2d_launch<double, double>(const double *, int, int, int64_t, double, double *, double *,
+                                          hipStream_t);
+
+}  // namespace svamd
+
+using namespace svamd;
+
+extern "C" int svamd_sat2d(const void *img, int dtype, int h, int w, int64_t pitch, double offset,
+                           void *s1, void *s2, void *stream)
+{
+    SV_REQUIRE(img && s1 && s2, SVAMD_ERR_INVALID, "svamd_sat2d: NULL pointer");
+    SV_REQUIRE(h > 0 && w > 0 && pitch >= w, SVAMD_ERR_INVALID, "svamd_sat2d: bad shape %dx%d pitch %lld",
+               h, w, (long long)pitch);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (dtype) {
+    case SVAMD_U8:
+        SV_REQUIRE(offset == std::floor(offset), SVAMD_ERR_INVALID,
+                   "svamd_sat2d: offset must be integral for uint8 input");
+        return sat2d_launch<uint8_t, int64_t>(static_cast<const uint8_t *>(img), h, w, pitch,
+                                              (int64_t)offset, static_cast<int64_t *>(s1),
+                                              static_cast<int64_t *>(s2), st);
+    case SVAMD_F32:
+        return sat2d_launch<float, double>(static_cast<const float *>(img), h, w, pitch, offset,
+                                           static_cast<double *>(s1), static_cast<double *>(s2), st);
+    case SVAMD_F64:
+        return sat2d_launch<double, double>(static_cast<const double *>(img), h, w, pitch, offset,
+                                            static_cast<double *>(s1), static_cast<double *>(s2), st);
+    default:
+        SV_REQUIRE(false, SVAMD_ERR_INVALID, "svamd_sat2d: unsupported dtype %d", dtype);
+    }
+}

@@ -1,0 +1,521 @@
+'''Stereo image comparison (template-window scan of a left image against search
+regions of a right image) on MI355X.
+
+Drop-in for the reference module of the same name (reference
+sv_image_comparison.py:1-380): same functions, arguments, module-level knobs,
+returned dict/list/tuple structure, exceptions and log lines.  The window and
+region enumeration stays on the host; every (template, region) correlation of
+a stage, its maximum and the per-window selection rule run on the GPU in two
+launches (libsvamd: svamd_scan_pairs, svamd_scan_fold).
+'''
+import numpy as np
+
+import correlation_spectral
+from correlation_spectral import cross_correlate_2d_spectral as x_corr_2d
+from utils import max_pos
+import _native as nv
+
+# Amount by which the correlation of a non-central region must exceed that of
+# the central one to register a displacement (reference sv_image_comparison.py:11)
+CENTRE_TOL = 0.01
+
+# Plot every correlation surface (reference :15); forces the pair-at-a-time path
+PLOT_XCORR = False
+
+# True / False / 'nonzero': which per-window summaries are printed (reference :19)
+LOG_WINDOW_SUMMARY = 'nonzero'
+
+# Arithmetic of the batched correlations: 'mixed' = float32 multiply-accumulate,
+# with every window whose selection came within GUARD_BAND of flipping
+# re-evaluated in float64; 'fp64' = float64 throughout; 'fp32' = no re-check.
+SCAN_PRECISION = 'mixed'
+GUARD_BAND = 1e-4
+
+_REFERENCE_CORRELATOR = x_corr_2d
+
+
+# ---------------------------------------------------------------------------
+# geometry (host)
+# ---------------------------------------------------------------------------
+def get_window_boundaries(x, y, x_window, y_window, image_width, image_height):
+    '''Clipped integer box (x_start, x_end, y_start, y_end) of a window given by
+    centre and size, or None when it lies outside the image (reference
+    sv_image_comparison.py:283-298).'''
+    half_w, half_h = x_window / 2, y_window / 2
+    if x + half_w <= 0 or y + half_h <= 0 or x - half_w > image_width or y - half_h > image_height:
+        return None
+    return (int(max(x - half_w, 0)), int(min(x + half_w, image_width)),
+            int(max(y - half_h, 0)), int(min(y + half_h, image_height)))
+
+
+def region_pairs(x_centre, x_window, y_centre, y_window, scheme, shift_size):
+    '''Centres of the candidate regions of one window: the window's own centre
+    first, then the scheme grid row by row (reference :119-141).'''
+    if scheme[0] % 2 != 1 or scheme[1] % 2 != 1:
+        raise Exception('Scheme dimensions must be odd.')
+    x_span_hw = (shift_size[0] if shift_size[0] else x_window) * (scheme[0] - 1) / 2
+    y_span_hw = (shift_size[1] if shift_size[1] else y_window) * (scheme[1] - 1) / 2
+    x_vec = np.linspace(x_centre - x_span_hw, x_centre + x_span_hw, scheme[0])
+    y_vec = np.linspace(y_centre - y_span_hw, y_centre + y_span_hw, scheme[1])
+    pairs = [(x_centre, y_centre)]
+    pairs.extend((x, y) for y in y_vec for x in x_vec if not (x == x_centre and y == y_centre))
+    return pairs
+
+
+def region_partition_pairs(x_centre, x_window, y_centre, y_window, factor):
+    '''Centres of the factor x factor sub-cells of a box (reference :193-204).'''
+    x_vec = np.linspace(x_centre - x_window / 2, x_centre + x_window / 2, 2 * factor + 1)[1::2]
+    y_vec = np.linspace(y_centre - y_window / 2, y_centre + y_window / 2, 2 * factor + 1)[1::2]
+    return [(x, y) for y in y_vec for x in x_vec]
+
+
+def _regions_for(centres, x_window, y_window, region_image):
+    '''target_regions list and the matching boxes for a list of centres.'''
+    image_height, image_width = region_image.shape
+    regions, boxes = [], []
+    for _x, _y in centres:
+        bounds = get_window_boundaries(_x, _y, x_window, y_window, image_width, image_height)
+        if bounds is None:
+            continue
+        x_start, x_end, y_start, y_end = bounds
+        regions.append({
+            'centre': (_x, _y),
+            'size': (x_end - x_start, y_end - y_start),
+            'image_slice': region_image[y_start:y_end, x_start:x_end],
+        })
+        boxes.append(bounds)
+    return regions, boxes
+
+
+def _stage0_windows(template_image, region_image, x_window, y_window, scheme, scheme_shift_size,
+                    window_overlap):
+    '''Windows of the first stage plus, per window, the template box and the
+    region boxes (x_start, x_end, y_start, y_end).'''
+    image_height, image_width = region_image.shape
+    if template_image.shape[0] != image_height or template_image.shape[1] != image_width:
+        raise Exception('Dimensions of template and region images must match')
+    x_stride = int(x_window * (1 - window_overlap))
+    y_stride = int(y_window * (1 - window_overlap))
+    windows, template_boxes, region_boxes = {}, [], []
+    window_id = 0
+    y = row = 0
+    while y < image_height:
+        x = column = 0
+        while x < image_width:
+            centre = (x + x_window / 2, y + y_window / 2)
+            regions, boxes = _regions_for(
+                region_pairs(centre[0], x_window, centre[1], y_window, scheme, scheme_shift_size),
+                x_window, y_window, region_image)
+            windows[window_id] = {
+                'row': row,
+                'column': column,
+                'centre': centre,
+                'size': (x_window, y_window),
+                'image_slice': template_image[y:y + y_window, x:x + x_window],
+                'target_regions': regions,
+            }
+            template_boxes.append((x, min(x + x_window, image_width), y, min(y + y_window, image_height)))
+            region_boxes.append(boxes)
+            window_id += 1
+            x += x_stride
+            column += 1
+        y += y_stride
+        row += 1
+    return windows, template_boxes, region_boxes
+
+
+def whole_image_search_regions(template_image, region_image, x_window, y_window,
+        scheme=(1, 3), scheme_shift_size=(0, 0), window_overlap=0):
+    '''Tiles the template image into windows and lists, for each, the search
+    regions of the region image given by the scheme (reference :143-191).'''
+    return _stage0_windows(template_image, region_image, x_window, y_window, scheme,
+                           scheme_shift_size, window_overlap)[0]
+
+
+def _multi_pass_regions(template_window_info, x_centre, y_centre, size, region_image, factor):
+    x_window, y_window = size
+    regions, boxes = _regions_for(
+        region_partition_pairs(x_centre, factor * x_window, y_centre, factor * y_window, factor),
+        x_window, y_window, region_image)
+    return {**template_window_info, 'target_regions': regions}, boxes
+
+
+def multi_pass_search_regions(template_window_info, x_centre, y_centre, size,
+        region_image, factor):
+    '''Search regions of a later stage: the factor x factor partition of a box of
+    factor * size centred on the previous stage's match (reference :206-227).'''
+    return _multi_pass_regions(template_window_info, x_centre, y_centre, size, region_image, factor)[0]
+
+
+# ---------------------------------------------------------------------------
+# correlation + selection (device)
+# ---------------------------------------------------------------------------
+def _batched_path_available():
+    return x_corr_2d is _REFERENCE_CORRELATOR and not PLOT_XCORR
+
+
+def _select(tbase, rbase, desc, is_centre, skip, win_off, threshold, max_side):
+    '''Runs every pair and the selection rule on the GPU.  desc: P x 8 int64,
+    win_off: nwin + 1 offsets.  Returns (best_pair, best_val) as numpy arrays.'''
+    torch = nv.torch_cuda()
+    npairs, nwin = len(desc), len(win_off) - 1
+    if nwin == 0:
+        return np.zeros(0, np.int64), np.zeros(0)
+    min_std = float(correlation_spectral.MIN_ST_DEV)
+    min_diff = float(correlation_spectral.MIN_MEAN_DIFF)
+    d_desc = nv.to_device(desc)
+    d_centre = nv.to_device(is_centre.astype(np.uint8))
+    d_skip = nv.to_device(skip.astype(np.uint8))
+    d_off = nv.to_device(win_off.astype(np.int64))
+    corr = nv.empty(max(npairs, 1), torch.float64)
+    best_pair = nv.empty(nwin, torch.int64)
+    best_val = nv.empty(nwin, torch.float64)
+    margin = nv.empty(nwin, torch.float64)
+    stream = nv.stream_ptr()
+
+    def pairs(desc_dev, count, precision, out):
+        nv.call('svamd_scan_pairs', nv.ptr(tbase), nv.ptr(rbase), nv.ptr(desc_dev), count, max_side,
+                min_std, min_diff, precision, nv.ptr(out), None, None, None, stream)
+
+    def fold():
+        nv.call('svamd_scan_fold', nv.ptr(corr), nv.ptr(d_centre), nv.ptr(d_skip), nv.ptr(d_off), nwin,
+                float(threshold), float(CENTRE_TOL), nv.ptr(best_pair), nv.ptr(best_val),
+                nv.ptr(margin), stream)
+
+    if SCAN_PRECISION not in ('mixed', 'fp64', 'fp32'):
+        raise ValueError(f'unknown SCAN_PRECISION {SCAN_PRECISION!r}')
+    pairs(d_desc, npairs, nv.ACC_F64 if SCAN_PRECISION == 'fp64' else nv.ACC_F32, corr)
+    fold()
+    if SCAN_PRECISION == 'mixed' and npairs:
+        close = (margin < GUARD_BAND).cpu().numpy()
+        if close.any():
+            # pairs of the windows whose selection was within the guard band
+            counts = np.diff(win_off)
+            redo = np.repeat(close, counts).nonzero()[0]
+            if redo.size:
+                d_redo = nv.to_device(redo.astype(np.int64))
+                sub = d_desc.view(-1, 8).index_select(0, d_redo).contiguous()
+                exact = nv.empty(redo.size, torch.float64)
+                pairs(sub, int(redo.size), nv.ACC_F64, exact)
+                corr.index_copy_(0, d_redo, exact)
+                fold()
+    return best_pair.cpu().numpy(), best_val.cpu().numpy()
+
+
+def _log_summary(window_id, centre, corr_max, corr_max_pos):
+    dp_x = corr_max_pos[0] - centre[0]
+    dp_y = corr_max_pos[1] - centre[1]
+    if LOG_WINDOW_SUMMARY == True or \
+            (LOG_WINDOW_SUMMARY == 'nonzero' and (dp_x != 0 or dp_y != 0)):
+        print(f'Window {window_id}: '
+              f'centre at {centre}, '
+              f'max correlation of {round(corr_max, 5)} at {corr_max_pos}, '
+              f'shift of ({dp_x}, {dp_y})')
+
+
+def _image_scan_pairwise(window_info, window_id, corr_threshold):
+    '''One correlation at a time through the module-level `x_corr_2d` hook: used
+    when that hook has been replaced, when surfaces are to be plotted, or when a
+    window is larger than the batched kernel's tile.'''
+    template = window_info['image_slice']
+    centre = window_info['centre']
+    window_corr_max = 0
+    window_corr_max_pos = centre
+    for region_info in window_info['target_regions']:
+        target_centre = region_info['centre']
+        if region_info['image_slice'].size == 0:
+            continue
+        x_corr = x_corr_2d(template, region_info['image_slice'])
+        corr_max = np.max(x_corr)
+        is_centre = target_centre == centre
+        bar = window_corr_max if is_centre else window_corr_max + CENTRE_TOL
+        if corr_max > corr_threshold and (corr_max >= bar if is_centre else corr_max > bar):
+            window_corr_max = corr_max
+            window_corr_max_pos = target_centre
+        if PLOT_XCORR:
+            _plot_pair(template, region_info, centre, x_corr, corr_max)
+    _log_summary(window_id, centre, window_corr_max, window_corr_max_pos)
+    return window_corr_max_pos, window_corr_max
+
+
+def _plot_pair(template, region_info, centre, x_corr, corr_max):
+    from matplotlib import pyplot as plt
+    from matplotlib.patches import Circle
+    local = max_pos(x_corr)
+    figure = plt.figure()
+    for k, (title, data) in enumerate((
+            (f'Template; centre at {centre}', template),
+            (f'Target region; centre at {region_info["centre"]}', region_info['image_slice']),
+            (f'Max XC of {round(corr_max, 4)} at local pos {tuple(reversed(local))}', x_corr))):
+        ax = figure.add_subplot(1, 3, k + 1)
+        ax.set_title(title)
+        if k == 2:
+            ax.add_patch(Circle(local, radius=1, color='red'))
+        plt.imshow(data)
+    plt.show()
+
+
+def _max_side(*shapes):
+    return max((max(s) for s in shapes if len(s)), default=0)
+
+
+def image_scan(window_info, window_id, corr_threshold=0):
+    '''Correlates one window with each of its target regions and returns the
+    centre of the selected region and its maximum correlation; (window centre,
+    0) when no region qualifies (reference sv_image_comparison.py:229-281).'''
+    template = np.asarray(window_info['image_slice'])
+    regions = window_info['target_regions']
+    centre = window_info['centre']
+    sides = _max_side(template.shape, *(np.shape(r['image_slice']) for r in regions))
+    if not _batched_path_available() or sides > nv.PAIR_MAX_SIDE or template.size == 0:
+        return _image_scan_pairwise(window_info, window_id, corr_threshold)
+
+    # pack the template and the regions into one float64 buffer
+    chunks = [np.ascontiguousarray(template, dtype=np.float64).ravel()]
+    offset = template.size
+    th, tw = template.shape
+    desc = np.zeros((len(regions), 8), dtype=np.int64)
+    skip = np.zeros(len(regions), dtype=bool)
+    is_centre = np.zeros(len(regions), dtype=bool)
+    for i, region_info in enumerate(regions):
+        sl = np.asarray(region_info['image_slice'])
+        skip[i] = sl.size == 0
+        is_centre[i] = region_info['centre'] == centre
+        rh, rw = sl.shape if sl.ndim == 2 else (0, 0)
+        desc[i] = (0, tw, th, tw, offset, rw, rh, rw)
+        chunks.append(np.ascontiguousarray(sl, dtype=np.float64).ravel())
+        offset += sl.size
+    if len(regions) == 0:
+        _log_summary(window_id, centre, 0, centre)
+        return centre, 0
+    buf = nv.to_device(np.concatenate(chunks))
+    best_pair, best_val = _select(buf, buf, desc, is_centre, skip, np.array([0, len(regions)]),
+                                  corr_threshold, max(sides, 1))
+    if best_pair[0] < 0:
+        pos, val = centre, 0
+    else:
+        pos, val = regions[int(best_pair[0])]['centre'], float(best_val[0])
+    _log_summary(window_id, centre, val, pos)
+    return pos, val
+
+
+def _box_desc(template_box, region_boxes, width_t, width_r):
+    '''Descriptor rows {t_off, t_pitch, t_h, t_w, r_off, r_pitch, r_h, r_w} of one
+    template box against several region boxes, all inside the two images.'''
+    tx0, tx1, ty0, ty1 = template_box
+    rows = np.empty((len(region_boxes), 8), dtype=np.int64)
+    if len(region_boxes):
+        rb = np.asarray(region_boxes, dtype=np.int64).reshape(-1, 4)
+        rows[:, 0] = ty0 * width_t + tx0
+        rows[:, 1] = width_t
+        rows[:, 2] = ty1 - ty0
+        rows[:, 3] = tx1 - tx0
+        rows[:, 4] = rb[:, 2] * width_r + rb[:, 0]
+        rows[:, 5] = width_r
+        rows[:, 6] = rb[:, 3] - rb[:, 2]
+        rows[:, 7] = rb[:, 1] - rb[:, 0]
+    return rows
+
+
+class _StageBatch:
+    '''Accumulates the (template, regions) groups of one stage for a single
+    pair of launches.'''
+
+    def __init__(self, width_t, width_r):
+        self.width_t, self.width_r = width_t, width_r
+        self.desc, self.centre, self.offsets = [], [], [0]
+
+    def add(self, template_box, centre, regions, region_boxes):
+        self.desc.append(_box_desc(template_box, region_boxes, self.width_t, self.width_r))
+        self.centre.append(np.fromiter((r['centre'] == centre for r in regions), dtype=bool,
+                                       count=len(regions)))
+        self.offsets.append(self.offsets[-1] + len(regions))
+
+    def max_side(self):
+        d = np.concatenate(self.desc) if self.desc else np.zeros((0, 8), np.int64)
+        return int(d[:, [2, 3, 6, 7]].max()) if len(d) else 0
+
+    def run(self, left_dev, right_dev, threshold):
+        desc = np.concatenate(self.desc) if self.desc else np.zeros((0, 8), np.int64)
+        centre = np.concatenate(self.centre) if self.centre else np.zeros(0, bool)
+        skip = (desc[:, 6] <= 0) | (desc[:, 7] <= 0)
+        return _select(left_dev, right_dev, desc, centre, skip, np.asarray(self.offsets),
+                       threshold, max(self.max_side(), 1))
+
+
+def sequence_scan(left_image, right_image, scan_config):
+    '''Compares a left and a right image by window searching over the stages of
+    one sequence and returns one dict of windows per stage (reference
+    sv_image_comparison.py:21-117).'''
+    seq_results = []
+    image_width = left_image.shape[1]
+    image_height = left_image.shape[0]
+    print(f'Image width: {image_width}, height: {image_height}')
+    batched = _batched_path_available()
+    left_dev = right_dev = None
+
+    def resident():
+        nonlocal left_dev, right_dev
+        if left_dev is None:
+            left_dev = nv.to_device(np.ascontiguousarray(left_image, dtype=np.float64))
+            right_dev = nv.to_device(np.ascontiguousarray(right_image, dtype=np.float64))
+        return left_dev, right_dev
+
+    for stage, stage_config in enumerate(scan_config):
+        windows = {}
+        if stage == 0:
+            windows, template_boxes, region_boxes = _stage0_windows(
+                template_image=left_image,
+                region_image=right_image,
+                x_window=stage_config['window_width'],
+                y_window=stage_config['window_height'],
+                scheme=tuple(stage_config['scheme']),
+                scheme_shift_size=tuple(stage_config['scheme_shift_size']),
+                window_overlap=stage_config['window_overlap'],
+            )
+            threshold = stage_config['correlation_threshold']
+            for window_info in windows.values():
+                window_info['stage_centres'] = [window_info['centre']]
+                window_info['stage_sizes'] = [window_info['size']]
+            batch = _StageBatch(image_width, right_image.shape[1])
+            for (window_id, window_info), tbox, rboxes in zip(windows.items(), template_boxes,
+                                                              region_boxes):
+                batch.add(tbox, window_info['centre'], window_info['target_regions'], rboxes)
+            if batched and batch.max_side() <= nv.PAIR_MAX_SIDE:
+                best_pair, best_val = batch.run(*resident(), threshold)
+                for i, (window_id, window_info) in enumerate(windows.items()):
+                    centre = window_info['centre']
+                    if best_pair[i] < 0:
+                        pos, val = centre, 0
+                    else:
+                        local = int(best_pair[i]) - batch.offsets[i]
+                        pos, val = window_info['target_regions'][local]['centre'], float(best_val[i])
+                    _log_summary(window_id, centre, val, pos)
+                    window_info['dp_x'] = pos[0] - centre[0]
+                    window_info['dp_y'] = pos[1] - centre[1]
+            else:
+                for window_id, window_info in windows.items():
+                    pos, _ = _image_scan_pairwise(window_info, window_id, threshold)
+                    window_info['dp_x'] = pos[0] - window_info['centre'][0]
+                    window_info['dp_y'] = pos[1] - window_info['centre'][1]
+        else:
+            factor = stage_config['factor']
+            region_boxes = {}
+            for window_id, window_info in seq_results[stage - 1].items():
+                # windows without a displacement in the previous stage drop out
+                if (window_info['dp_x'] == 0 and window_info['dp_y'] == 0) or \
+                        len(window_info['stage_sizes']) < stage:
+                    continue
+                prev_w, prev_h = window_info['stage_sizes'][stage - 1]
+                window_info['stage_sizes'].append((int(prev_w / factor), int(prev_h / factor)))
+                prev_centre = window_info['stage_centres'][stage - 1]
+                windows[window_id], region_boxes[window_id] = _multi_pass_regions(
+                    template_window_info=window_info,
+                    x_centre=prev_centre[0] + window_info['dp_x'],
+                    y_centre=prev_centre[1] + window_info['dp_y'],
+                    size=window_info['stage_sizes'][stage],
+                    region_image=right_image,
+                    factor=factor,
+                )
+            # template partitions: sub-cells of the previous window, each still of
+            # the previous window's size
+            partitions = {}
+            batch = _StageBatch(image_width, right_image.shape[1])
+            for window_id, window_info in windows.items():
+                x_centre, y_centre = window_info['stage_centres'][stage - 1]
+                x_window, y_window = window_info['stage_sizes'][stage - 1]
+                parts = []
+                for _x, _y in region_partition_pairs(x_centre, x_window, y_centre, y_window, factor):
+                    bounds = get_window_boundaries(_x, _y, x_window, y_window, image_width, image_height)
+                    if bounds is None:
+                        continue
+                    x_start, x_end, y_start, y_end = bounds
+                    parts.append({
+                        'centre': (_x, _y),
+                        'size': (x_end - x_start, y_end - y_start),
+                        'image_slice': left_image[y_start:y_end, x_start:x_end],
+                    })
+                    batch.add(bounds, (_x, _y), window_info['target_regions'], region_boxes[window_id])
+                partitions[window_id] = parts
+            use_batch = batched and batch.max_side() <= nv.PAIR_MAX_SIDE and \
+                all(p['image_slice'].size for parts in partitions.values() for p in parts)
+            if use_batch:
+                best_pair, best_val = batch.run(*resident(), 0)
+            group = 0
+            for window_id, window_info in windows.items():
+                window_corr_max = 0
+                for wp in partitions[window_id]:
+                    if use_batch:
+                        if best_pair[group] < 0:
+                            pos, corr_max = wp['centre'], 0
+                        else:
+                            local = int(best_pair[group]) - batch.offsets[group]
+                            pos = window_info['target_regions'][local]['centre']
+                            corr_max = float(best_val[group])
+                        _log_summary(window_id, wp['centre'], corr_max, pos)
+                    else:
+                        pos, corr_max = _image_scan_pairwise(
+                            {**wp, 'target_regions': window_info['target_regions']}, window_id, 0)
+                    group += 1
+                    if corr_max > window_corr_max:
+                        window_corr_max = corr_max
+                        window_info['centre'] = wp['centre']
+                        window_info['dp_x'] = pos[0] - wp['centre'][0]
+                        window_info['dp_y'] = pos[1] - wp['centre'][1]
+                        if len(window_info['stage_centres']) < stage + 1:
+                            window_info['stage_centres'].append(wp['centre'])
+                        else:
+                            window_info['stage_centres'][stage] = wp['centre']
+        seq_results.append(windows)
+    return seq_results
+
+
+# ---------------------------------------------------------------------------
+# plotting (host, matplotlib)
+# ---------------------------------------------------------------------------
+def plot_sequence_output(left_image, right_image, sequence_results,
+        max_shift_magnitude, shift_plot_type):
+    '''Overlays the window grid, the later-stage templates / target regions and
+    the displacements of one sequence on the two images (counterpart of
+    reference sv_image_comparison.py:326-380).'''
+    from matplotlib import pyplot as plt
+    from matplotlib.patches import Rectangle
+
+    def box(centre, size, **kw):
+        corner = (centre[0] - int(size[0] / 2), centre[1] - int(size[1] / 2))
+        return Rectangle(corner, *size, **kw)
+
+    figure = plt.figure(figsize=(1, 2))
+    left_plot = figure.add_subplot(1, 2, 1)
+    left_plot.imshow(left_image)
+    right_plot = figure.add_subplot(1, 2, 2)
+    right_plot.imshow(right_image)
+    last = len(sequence_results) - 1
+    for stage, windows in enumerate(sequence_results):
+        for window_info in windows.values():
+            if len(window_info['stage_centres']) < stage + 1:
+                continue
+            if stage == 0:
+                x, y = window_info['centre']
+                for plot in (left_plot, right_plot):
+                    plot.add_patch(box((x, y), window_info['size'], linewidth=1, edgecolor='blue',
+                                       facecolor='none'))
+            else:
+                for region_info in window_info['target_regions']:
+                    for plot in (left_plot, right_plot):
+                        plot.add_patch(box(region_info['centre'], region_info['size'], linewidth=1,
+                                           edgecolor='green', facecolor='none'))
+                x, y = window_info['stage_centres'][stage]
+                left_plot.add_patch(box((x, y), window_info['stage_sizes'][stage], linewidth=1,
+                                        edgecolor='cyan', facecolor='none'))
+            if stage == last and (window_info['dp_x'] or window_info['dp_y']):
+                if shift_plot_type == 'arrows':
+                    left_plot.arrow(x, y, window_info['dp_x'], window_info['dp_y'], head_width=5,
+                                    head_length=5, edgecolor='red', facecolor='red')
+                elif shift_plot_type == 'boxes':
+                    magnitude = np.sqrt(window_info['dp_x'] ** 2 + window_info['dp_y'] ** 2)
+                    colour = (1, 0, 0) if stage == 0 else (0, 1, 1)
+                    left_plot.add_patch(box((x, y), window_info['stage_sizes'][stage], linewidth=1,
+                                            edgecolor='none',
+                                            facecolor=(*colour, min(magnitude / max_shift_magnitude, 1))))
+    plt.show()

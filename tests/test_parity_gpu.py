@@ -1,0 +1,384 @@
+'''Parity of the HIP path (through the host modules and the C ABI) with the golden
+vectors taken from the reference and with the CPU oracle.  Needs an MI355X.
+
+Tolerances: NCC surfaces are compared at 1e-5 relative with the scale floored
+at 1 (surfaces live on [-1, 1]); positions, disparities and selected regions
+must match exactly.
+'''
+import io
+import contextlib
+import json
+
+import numpy as np
+import pytest
+
+from helpers import assert_surface_close, golden, rand_pair
+
+pytestmark = pytest.mark.gpu
+
+SURFACE_TOL = 1e-5
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+@pytest.fixture(scope='module')
+def mods():
+    import correlation
+    import correlation_spectral
+    import sv_image_comparison
+    import utils
+    import band_scan
+    import _native
+    _native.torch_cuda()
+    return dict(c=correlation, s=correlation_spectral, v=sv_image_comparison, u=utils, b=band_scan,
+                n=_native)
+
+
+# ---- a1 ------------------------------------------------------------------------
+def test_g1_spatial_template_region(mods):
+    g = golden('g1_spatial_template_region')
+    out = quiet(mods['c'].cross_correlate_2d, g['template'], g['region'], 5, 5)
+    assert_surface_close(out, g['surface'], SURFACE_TOL, 'g1')
+    assert tuple(mods['u'].max_pos(out, 5, 5)) == tuple(g['max_pos'])
+
+
+def test_spatial_prints_reference_progress_lines(mods, capsys):
+    mods['c'].cross_correlate_2d(np.ones((3, 3)) * np.arange(3), np.arange(25 * 9, dtype=np.uint8).reshape(25, 9))
+    lines = capsys.readouterr().out.split('\n')
+    assert lines[:3] == ['0 / 25', '10 / 25', '20 / 25']
+
+
+def test_g2_spatial_nan_template(mods):
+    g = golden('g2_spatial_nan_template')
+    for k in 'abc':
+        sx, sy = (int(v) for v in g[f'step_{k}'])
+        out = quiet(mods['c'].cross_correlate_2d, g['template'], g[f'region_{k}'], sx, sy)
+        assert_surface_close(out, g[f'surface_{k}'], SURFACE_TOL, f'g2{k}')
+
+
+def test_g3_spatial_band(mods):
+    g = golden('g3_spatial_band')
+    for i in range(len(g['templates'])):
+        out = quiet(mods['c'].cross_correlate_2d, g['templates'][i].astype(np.float64), g['bands'][i])
+        assert_surface_close(out, g['surfaces'][i], SURFACE_TOL, f'g3[{i}]')
+        assert int(np.nanargmax(out[0, :257])) == int(np.nanargmax(g['surfaces'][i][0, :257]))
+
+
+def test_spatial_float_region_and_constant_patches(mods, oracle):
+    rng = np.random.default_rng(11)
+    region = rng.random((40, 56))
+    region[5:20, 8:30] = 0.5           # constant snapshot -> NaN outputs
+    template = rng.random((9, 13))
+    template[2, 3] = np.nan
+    out = quiet(mods['c'].cross_correlate_2d, template, region, 2, 3)
+    assert_surface_close(out, oracle.cross_correlate_2d(template, region, 2, 3), SURFACE_TOL, 'float region')
+    flat_t = np.full((4, 4), 7.0)
+    out = quiet(mods['c'].cross_correlate_2d, flat_t, (region * 255).astype(np.uint8))
+    assert np.isnan(out).all()
+
+
+def test_spatial_template_exceeds_region(mods):
+    with pytest.raises(Exception, match='Dimensions of template must not exceed those of region.'):
+        mods['c'].cross_correlate_2d(np.zeros((5, 5)), np.zeros((4, 9), np.uint8))
+
+
+# ---- a2 ------------------------------------------------------------------------
+def test_g4_spectral_small(mods):
+    g = golden('g4_spectral_small')
+    tags = sorted(k[:-4] for k in g.files if k.endswith('_out'))
+    for tag in tags:
+        out = mods['s'].cross_correlate_2d_spectral(g[f'{tag}_t'], g[f'{tag}_r'])
+        assert_surface_close(out, g[f'{tag}_out'], SURFACE_TOL, tag)
+
+
+def test_g4_spectral_images(mods):
+    g = golden('g4_spectral_images')
+    out = mods['s'].cross_correlate_2d_spectral(g['template'], g['region'])
+    assert out.shape == g['region'].shape and out.dtype == np.float64
+    assert_surface_close(out.ravel()[g['sample_idx']], g['sample_val'], SURFACE_TOL, 'samples')
+    assert_surface_close(out[::16], g['rows'], SURFACE_TOL, 'rows')
+    assert tuple(mods['u'].max_pos(out)) == tuple(g['max_pos'])
+    assert abs(out.max() - float(g['max_val'])) < SURFACE_TOL
+
+
+def test_g4_spectral_rand256(mods):
+    g = golden('g4_spectral_rand256')
+    t, r, idx = rand_pair(256)
+    out = mods['s'].cross_correlate_2d_spectral(t, r)
+    assert_surface_close(out.ravel()[idx], g['sample_val'], SURFACE_TOL, 'rand256')
+    assert int(np.argmax(out)) == int(g['argmax'])
+
+
+def test_spectral_large_low_std_branches(mods):
+    t = np.full((70, 70), 3.0)
+    r = np.full((80, 90), 3.0)
+    assert np.all(mods['s'].cross_correlate_2d_spectral(t, r) == 1.0)
+    assert np.all(mods['s'].cross_correlate_2d_spectral(t, r + 1) == 0.0)
+
+
+# ---- 1D ------------------------------------------------------------------------
+def close_1d(got, want, what):
+    scale = np.max(np.abs(want))
+    assert got.shape == want.shape
+    assert np.max(np.abs(got - want)) <= SURFACE_TOL * scale, what
+
+
+def test_g5_1d(mods):
+    g = golden('g5_1d')
+    c, s = mods['c'], mods['s']
+    close_1d(quiet(c.cross_correlate_1d, g['v1'], g['v2']), g['xc'], 'xc')
+    close_1d(quiet(c.cross_correlate_1d, g['v1'], g['v2'], True), g['xc_norm'], 'xc_norm')
+    raw = quiet(c.cross_correlate_1d_raw, list(g['v1']), list(g['v2']), True)
+    assert isinstance(raw, list)
+    close_1d(np.array(raw), g['xc_raw_norm'], 'raw')
+    spec = s.cross_correlate_1d_spectral(g['v1'], g['v2'])
+    close_1d(spec, g['xc_spec'], 'spec')
+    close_1d(s.cross_correlate_1d_spectral(g['t_short'], g['s_long']), g['xc_spec_uneq'], 'uneq')
+    assert int(np.argmax(spec)) == 216 == int(np.argmax(quiet(c.cross_correlate_1d, g['v1'], g['v2'])))
+    x = np.arange(0, 4 * np.pi, np.pi / 2000)
+    full = quiet(c.cross_correlate_1d, np.cos(x), -np.sin(x), True)
+    close_1d(full[::16], g['cs_xc_norm_dec'], 'cos/sin')
+    assert abs(int(np.argmax(full)) - int(g['cs_xc_norm_argmax'])) <= 1
+    fs = s.cross_correlate_1d_spectral(np.cos(x), -np.sin(x))
+    close_1d(fs[::16], g['cs_spec_dec'], 'cos/sin spectral')
+
+
+def test_1d_unequal_raises(mods):
+    with pytest.raises(Exception, match='unequal length'):
+        mods['c'].cross_correlate_1d(np.zeros(4), np.zeros(5))
+
+
+# ---- a11 -----------------------------------------------------------------------
+def test_max_pos(mods):
+    a = np.array([[1.0, np.nan, 3.0], [3.0, 2.0, np.nan]])
+    assert mods['u'].max_pos(a) == (2, 0)
+    assert mods['u'].max_pos(a, 5, 7) == (14, 0)
+    with pytest.raises(ValueError):
+        mods['u'].max_pos(np.full((2, 2), np.nan))
+
+
+# ---- scans ---------------------------------------------------------------------
+def check_scan(mods, g, left, right, precisions=('mixed',)):
+    v = mods['v']
+    cfg = json.loads(str(g['config']))
+    for precision in precisions:
+        v.SCAN_PRECISION = precision
+        try:
+            for s in range(int(g['n_seq'])):
+                res = quiet(v.sequence_scan, left, right, cfg[s])
+                assert len(res) == len(cfg[s])
+                for st, windows in enumerate(res):
+                    want = g[f'seq{s}_stage{st}_windows']
+                    centres = g[f'seq{s}_stage{st}_centres']
+                    sizes = g[f'seq{s}_stage{st}_sizes']
+                    assert list(windows) == [int(i) for i in want[:, 0]]
+                    for i, w in enumerate(windows.values()):
+                        row = want[i]
+                        assert (w['row'], w['column']) == (int(row[1]), int(row[2]))
+                        assert w['centre'] == (row[3], row[4])
+                        assert (w['dp_x'], w['dp_y']) == (row[5], row[6]), (precision, s, st, i)
+                        assert len(w['target_regions']) == int(row[9])
+                        assert [tuple(c) for c in w['stage_centres']] == \
+                            [tuple(c) for c in centres[i, :int(row[7])]]
+                        assert [tuple(z) for z in w['stage_sizes']] == \
+                            [tuple(z) for z in sizes[i, :int(row[8])]]
+        finally:
+            v.SCAN_PRECISION = 'mixed'
+
+
+@pytest.mark.parametrize('cfg', ['scan_config_portal', 'scan_config', 'scan_config_example',
+                                 'scan_config_test_2'])
+def test_g6_cone_scans(mods, cfg):
+    im = golden('g6_cone_images')
+    check_scan(mods, golden(f'g6_cone_{cfg}'), im['left'] / 255.0, im['right'] / 255.0,
+               ('mixed', 'fp64') if cfg == 'scan_config_portal' else ('mixed',))
+
+
+@pytest.mark.parametrize('name', ['box', 'tuscany'])
+def test_g6_crops_test1(mods, name):
+    g = golden(f'g6_{name}256_scan_config_test_1')
+    check_scan(mods, g, g['left'] / 255.0, g['right'] / 255.0)
+
+
+def test_g9_multipass(mods):
+    im = golden('g6_cone_images')
+    check_scan(mods, golden('g9_cone_multipass'), im['left'] / 255.0, im['right'] / 255.0)
+
+
+def test_g7_dense_roll(mods):
+    g = golden('g7_dense_roll5')
+    check_scan(mods, g, g['left'], g['right'])
+
+
+def test_g8_dense_u8(mods):
+    g = golden('g8_dense_u8')
+    check_scan(mods, g, g['left'] / 255.0, g['right'] / 255.0)
+
+
+def test_image_scan_values_and_log(mods, capsys):
+    '''image_scan on reference-shaped window dicts: position, correlation value
+    and the summary line.'''
+    v = mods['v']
+    im = golden('g6_cone_images')
+    g = golden('g6_cone_scan_config_portal')
+    left, right = im['left'] / 255.0, im['right'] / 255.0
+    cfg = json.loads(str(g['config']))[0][0]
+    windows = v.whole_image_search_regions(left, right, cfg['window_width'], cfg['window_height'],
+                                           tuple(cfg['scheme']), tuple(cfg['scheme_shift_size']),
+                                           cfg['window_overlap'])
+    calls = g['seq0_calls']
+    moved = [int(c[0]) for c in calls if (c[1], c[2]) != windows[int(c[0])]['centre']][:6]
+    for wid in moved + [0, 1, 2]:
+        pos, val = v.image_scan(windows[wid], wid, cfg['correlation_threshold'])
+        want = calls[wid]
+        assert (pos[0], pos[1]) == (want[1], want[2])
+        assert abs(val - want[3]) < SURFACE_TOL
+    out = capsys.readouterr().out
+    assert out.count('Window ') == len(moved)
+    assert f'Window {moved[0]}: centre at {windows[moved[0]]["centre"]}, max correlation of' in out
+
+
+def test_scan_shape_errors(mods):
+    v = mods['v']
+    with pytest.raises(Exception, match='Scheme dimensions must be odd.'):
+        v.region_pairs(5, 10, 5, 10, (2, 1), (0, 0))
+    with pytest.raises(Exception, match='Dimensions of template and region images must match'):
+        v.whole_image_search_regions(np.zeros((4, 4)), np.zeros((4, 5)), 2, 2)
+
+
+def test_scan_correlator_hook(mods):
+    '''Replacing the module-level x_corr_2d hook routes every pair through it.'''
+    v = mods['v']
+    seen = []
+    orig = v.x_corr_2d
+
+    def hook(t, r):
+        seen.append(t.shape)
+        return orig(t, r)
+    rng = np.random.default_rng(1)
+    left = rng.random((24, 36))
+    cfg = [{'window_width': 12, 'window_height': 12, 'scheme': [3, 1], 'scheme_shift_size': [2, 0],
+            'window_overlap': 0, 'correlation_threshold': 0.2}]
+    want = quiet(v.sequence_scan, left, np.roll(left, 2, axis=1), cfg)
+    v.x_corr_2d = hook
+    try:
+        got = quiet(v.sequence_scan, left, np.roll(left, 2, axis=1), cfg)
+    finally:
+        v.x_corr_2d = orig
+    assert len(seen) > 0
+    assert [(w['dp_x'], w['dp_y']) for w in got[0].values()] == \
+        [(w['dp_x'], w['dp_y']) for w in want[0].values()]
+
+
+# ---- pairs kernel through the C ABI vs the oracle --------------------------------
+def test_scan_pairs_vs_oracle(mods, oracle):
+    import torch
+    nv = mods['n']
+    rng = np.random.default_rng(21)
+    H, W = 64, 96
+    left, right = rng.random((H, W)), rng.random((H, W))
+    right[10:22, 30:42] = 0.5                        # constant region -> NaN
+    left[40:52, 0:12] = 0.25                         # constant template -> ones/zeros
+    right[40:52, 0:12] = 0.25
+    boxes = []
+    for _ in range(200):
+        th, tw, rh, rw = rng.integers(1, 40, size=4)
+        ty, tx = rng.integers(0, H - th + 1), rng.integers(0, W - tw + 1)
+        ry, rx = rng.integers(0, H - rh + 1), rng.integers(0, W - rw + 1)
+        boxes.append((ty * W + tx, W, th, tw, ry * W + rx, W, rh, rw))
+    boxes.append((0, W, 12, 12, 10 * W + 30, W, 12, 12))
+    boxes.append((40 * W, W, 12, 12, 40 * W, W, 12, 12))
+    boxes.append((40 * W, W, 12, 12, 0, W, 12, 12))
+    boxes.append((0, W, 12, 12, 0, W, 0, 5))          # empty region
+    desc = np.array(boxes, dtype=np.int64)
+    want = np.empty(len(desc))
+    for p, d in enumerate(desc):
+        if d[6] == 0 or d[7] == 0:
+            want[p] = np.nan
+            continue
+        ty, tx = divmod(int(d[0]), W)
+        ry, rx = divmod(int(d[4]), W)
+        want[p] = oracle.cross_correlate_2d_spectral(left[ty:ty + d[2], tx:tx + d[3]],
+                                                     right[ry:ry + d[6], rx:rx + d[7]], want='max')
+    dl, dr, dd = nv.to_device(left), nv.to_device(right), nv.to_device(desc)
+    for precision, tol in ((nv.ACC_F32, SURFACE_TOL), (nv.ACC_F64, 1e-11)):
+        out = nv.empty(len(desc), torch.float64)
+        arg = nv.empty(len(desc), torch.int64)
+        nv.call('svamd_scan_pairs', nv.ptr(dl), nv.ptr(dr), nv.ptr(dd), len(desc), 40, 1e-4, 1e-9,
+                precision, nv.ptr(out), nv.ptr(arg), None, None, nv.stream_ptr())
+        assert_surface_close(out.cpu().numpy(), want, tol, f'pairs precision {precision}')
+
+
+# ---- dense band scan ---------------------------------------------------------------
+def synthetic_pair(h, w, seed, max_shift):
+    rng = np.random.default_rng(seed)
+    base = rng.integers(0, 256, size=(h, w + 2 * max_shift)).astype(np.float64)
+    k = np.array([1, 2, 1]) / 4
+    base = np.apply_along_axis(lambda v: np.convolve(v, k, mode='same'), 1, base)
+    base = np.clip(np.rint(base), 0, 255).astype(np.uint8)
+    left = base[:, max_shift:max_shift + w].copy()
+    right = np.empty_like(left)
+    for y0 in range(0, h, 16):
+        d = int(rng.integers(-max_shift, max_shift + 1))
+        right[y0:y0 + 16] = base[y0:y0 + 16, max_shift - d:max_shift - d + w]
+    right = np.clip(right.astype(np.int32) + rng.integers(-2, 3, size=right.shape), 0, 255).astype(np.uint8)
+    return left, right
+
+
+@pytest.mark.parametrize('win,h,w,md', [(31, 70, 300, 24), (31, 47, 140, 128), (15, 40, 90, 10),
+                                        (7, 33, 64, 5), (11, 30, 530, 3), (21, 50, 77, 9)])
+def test_band_scan_vs_oracle(mods, oracle, win, h, w, md):
+    left, right = synthetic_pair(h, w, win * 1000 + md, min(md, 12))
+    left[5:5 + win, 3:3 + win] = 200                     # a constant window
+    b = mods['b']
+    disp, val, scores = b.band_scan(left, right, win, win, md, want_scores=True)
+    odisp, oval, oscores = oracle.band_scan(left, right, win, win, md, want_scores=True)
+    assert_surface_close(scores, oscores, 1e-12, 'band scores')
+    assert np.array_equal(disp, odisp)
+    assert_surface_close(val, oval, 1e-12, 'band values')
+    # image_scan's rule
+    for thr in (0.0, 0.7):
+        disp, val = b.band_scan(left / 255.0, right / 255.0, win, win, md, correlation_threshold=thr)
+        odisp, oval = oracle.band_scan(left, right, win, win, md, mode='fold', threshold=thr)
+        assert np.array_equal(disp, odisp)
+        assert_surface_close(val, oval, 1e-12, 'band fold values')
+
+
+def test_band_scan_row_stride_and_sharding(mods, oracle):
+    left, right = synthetic_pair(90, 200, 5, 8)
+    b = mods['b']
+    odisp, oval = oracle.band_scan(left, right, 31, 31, 16, stride_y=3)
+    disp, val = b.band_scan(left, right, 31, 31, 16, row_stride=3)
+    assert np.array_equal(disp, odisp)
+    sc = b.BandScanner(90, 200, 31, 31, 16)
+    sc.upload(left, right)
+    sc.disp.fill_(-7)
+    sc.run(rows=(10, 37))
+    part = sc.disp.cpu().numpy()
+    full, _ = oracle.band_scan(left, right, 31, 31, 16)
+    assert np.array_equal(part[10:37], full[10:37])
+    assert np.all(part[:10] == -7) and np.all(part[37:] == -7)
+
+
+def test_band_scan_matches_reference_band_row(mods):
+    '''Row 0 of the reference's spatial NCC of a 31-row band = the band scan's
+    scores (golden g3).'''
+    g = golden('g3_spatial_band')
+    b = mods['b']
+    for i in range(len(g['templates'])):
+        left = np.zeros((31, 287), np.uint8)
+        left[:, 128:159] = g['templates'][i]
+        disp, val, scores = b.band_scan(left, g['bands'][i], 31, 31, 128, want_scores=True)
+        assert_surface_close(scores[0, 128], g['surfaces'][i][0, :257], 1e-12, 'band row 0')
+        assert disp[0, 128] == int(np.nanargmax(g['surfaces'][i][0, :257])) - 128
+
+
+def test_band_scan_rejects_unsupported(mods):
+    b = mods['b']
+    with pytest.raises(TypeError):
+        b.band_scan(np.random.default_rng(0).random((40, 40)), np.zeros((40, 40)), 7, 7, 3)
+    with pytest.raises(mods['n'].NativeError, match='no compiled kernel'):
+        b.band_scan(np.zeros((40, 40), np.uint8), np.zeros((40, 40), np.uint8), 8, 8, 3)
