@@ -15,7 +15,8 @@
 // window columns.  Its left tile and the matching band of the right image are
 // staged once in LDS as float32.  Wavefront w owns window row w; lane i owns the
 // 4 consecutive windows 4i..4i+3 and, per pass, 8 consecutive offsets: 32
-// accumulators per lane.  For each image row the lane walks the 34 columns its 4
+// accumulators per lane, held as 16 register pairs (two neighbouring windows
+// each) and updated by packed FMAs.  For each image row the lane walks the 34 columns its 4
 // windows span: one ds_read_b128 per 4 left pixels, one per 4 new right pixels,
 // up to 128 FMAs in between (about 50 FMAs per LDS read instruction), so the
 // loop is bound by the vector ALU, not by LDS.  Offsets are visited in ascending
@@ -103,13 +104,20 @@ __device__ __forceinline__ void load4(float *dst, const float *src)
     }
 }
 
-// acc[x][d] += sum over `rows` image rows and the window's columns of
-//              L[row][x + b] * R[row][x + b + d],  b < WIN_W
+typedef float float2v __attribute__((ext_vector_type(2)));
+
+// acc[p][d] = (window 2p, window 2p+1) at offset d:
+//   acc[x][d] += sum over `rows` image rows and the window's columns of
+//                L[row][x + b] * R[row][x + b + d],  b < WIN_W
 // lp / rp point at the lane's first left column / first right column (offset d = 0
-// of this pass) in the first row.
+// of this pass) in the first row.  Two neighbouring windows share every product
+// except at their outer columns, so the bulk of the work is issued as packed
+// v_pk_fma_f32 with both multiplicands broadcast (op_sel), which lets a single
+// wavefront keep its SIMD's FMA pipe full; the outer columns use scalar FMAs.
 template <int WIN_W, int D, bool ALIGNED>
 __device__ __forceinline__ void accumulate(const float *__restrict__ lp, const float *__restrict__ rp,
-                                           int lpitch, int rpitch, int rows, float (&acc)[BAND_X][D])
+                                           int lpitch, int rpitch, int rows,
+                                           float2v (&acc)[BAND_X / 2][D])
 {
     constexpr int NU = WIN_W + BAND_X - 1;       // left columns touched by the lane's windows
     constexpr int NCL = (NU + 3) / 4;            // ... in groups of four
@@ -132,11 +140,24 @@ __device__ __forceinline__ void accumulate(const float *__restrict__ lp, const f
                 const int u = 4 * c + i;
                 if (u < NU) {
 #pragma unroll
-                    for (int x = 0; x < BAND_X; ++x) {
-                        if (x <= u && u < x + WIN_W) {
+                    for (int p = 0; p < BAND_X / 2; ++p) {
+                        const bool lo = 2 * p <= u && u < 2 * p + WIN_W;          // window 2p
+                        const bool hi = 2 * p + 1 <= u && u < 2 * p + 1 + WIN_W;  // window 2p+1
+                        if (lo && hi) {
+                            const float2v l2 = {lv[i], lv[i]};
+#pragma unroll
+                            for (int d = 0; d < D; ++d) {
+                                const float2v r2 = {rv[u + d], rv[u + d]};
+                                acc[p][d] = __builtin_elementwise_fma(l2, r2, acc[p][d]);
+                            }
+                        } else if (lo) {
 #pragma unroll
                             for (int d = 0; d < D; ++d)
-                                acc[x][d] = fmaf(lv[i], rv[u + d], acc[x][d]);
+                                acc[p][d].x = fmaf(lv[i], rv[u + d], acc[p][d].x);
+                        } else if (hi) {
+#pragma unroll
+                            for (int d = 0; d < D; ++d)
+                                acc[p][d].y = fmaf(lv[i], rv[u + d], acc[p][d].y);
                         }
                     }
                 }
@@ -158,7 +179,7 @@ struct LaneState {
 // k0: offset index (0 .. nd-1) of acc[.][0]; centre_pass: this pass evaluates the
 // centre offset ahead of the ascending sweep (selection-rule mode only).
 template <int D>
-__device__ __forceinline__ void finish_pass(const BandGeom &g, const float (&acc)[BAND_X][D], int k0,
+__device__ __forceinline__ void finish_pass(const BandGeom &g, const float2v (&acc)[BAND_X / 2][D], int k0,
                                             int kend, bool centre_pass, int wy, int xbase,
                                             const int32_t *__restrict__ wsum_r,
                                             const double *__restrict__ winv_r, LaneState &st,
@@ -179,7 +200,8 @@ __device__ __forceinline__ void finish_pass(const BandGeom &g, const float (&acc
             double s = NAN;
             if (valid) {
                 const double s1r = (double)wsum_r[srow + xr];
-                const double num = fma(n, (double)acc[x][d], -(st.s1l[x] * s1r));
+                const float cross = (x & 1) ? acc[x / 2][d].y : acc[x / 2][d].x;
+                const double num = fma(n, (double)cross, -(st.s1l[x] * s1r));
                 s = num * st.invl[x] * winv_r[srow + xr];
             }
             if (scores && wvalid && kvalid)
@@ -246,7 +268,7 @@ band_scan_kernel(BandGeom g, const uint8_t *__restrict__ left, const uint8_t *__
         stage_tile(right, g.H, g.W, y0, g.tile_rows, x0, g.lpitch, Rt);
         __syncthreads();
         if (active) {
-            float acc[BAND_X][1] = {};
+            float2v acc[BAND_X / 2][1] = {};
             accumulate<WIN_W, 1, true>(lp, Rt + lrow * g.lpitch + BAND_X * lane, g.lpitch, g.lpitch,
                                        g.win_h, acc);
             finish_pass<1>(g, acc, g.max_disp, g.nd, true, wy, xbase, wsum_r, winv_r, st, nullptr);
@@ -263,12 +285,12 @@ band_scan_kernel(BandGeom g, const uint8_t *__restrict__ left, const uint8_t *__
         const float *rp = Rt + lrow * g.rpitch + BAND_X * lane;
         int k = k0;
         for (; k + BAND_D <= kend; k += BAND_D) {
-            float acc[BAND_X][BAND_D] = {};
+            float2v acc[BAND_X / 2][BAND_D] = {};
             accumulate<WIN_W, BAND_D, true>(lp, rp + (k - k0), g.lpitch, g.rpitch, g.win_h, acc);
             finish_pass<BAND_D>(g, acc, k, kend, false, wy, xbase, wsum_r, winv_r, st, scores);
         }
         for (; k < kend; ++k) {  // fewer than 8 offsets left in this chunk
-            float acc[BAND_X][1] = {};
+            float2v acc[BAND_X / 2][1] = {};
             accumulate<WIN_W, 1, false>(lp, rp + (k - k0), g.lpitch, g.rpitch, g.win_h, acc);
             finish_pass<1>(g, acc, k, kend, false, wy, xbase, wsum_r, winv_r, st, scores);
         }
