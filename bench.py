@@ -72,7 +72,7 @@ def cpu_baseline(height, width, seed):
     on a crop of the same synthetic pair.'''
     from oracle import ncc_oracle
     ncc_oracle.build()
-    ch, cw = 31 + 383, 31 + 1023        # 384 window rows x 1024 window columns
+    ch, cw = 31 + 1023, 31 + 1023       # 1024 x 1024 windows
     left, right = synthetic_pair(ch, cw, seed)
     cores = ncc_oracle.max_threads()
     t0 = time.perf_counter()

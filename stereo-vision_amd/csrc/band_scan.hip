@@ -30,9 +30,12 @@ namespace svamd {
 constexpr int BAND_X = 4;                 // windows per lane
 constexpr int BAND_D = 8;                 // offsets per pass
 constexpr int BAND_TX = WAVE * BAND_X;    // window columns per tile
-constexpr int BAND_WAVES = 16;            // window rows per tile
+#ifndef SVAMD_BAND_WAVES
+#define SVAMD_BAND_WAVES 16
+#endif
+constexpr int BAND_WAVES = SVAMD_BAND_WAVES;  // window rows per tile
 constexpr int BAND_THREADS = BAND_WAVES * WAVE;
-constexpr int BAND_LDS_LIMIT = 160 * 1024;
+constexpr int BAND_LDS_LIMIT = 160 * 1024 - 256;   // dynamic LDS; the rest holds the pace counters
 
 struct BandGeom {
     int H, W, win_w, win_h, stride_y, max_disp, nd;
@@ -87,24 +90,111 @@ __device__ __forceinline__ void stage_tile(const uint8_t *__restrict__ img, int 
     }
 }
 
-template <bool ALIGNED>
-__device__ __forceinline__ void load4(float *dst, const float *src)
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+
+// acc.x += l * r; acc.y += l * r with l = half LH of lpair, r = half RH of rpair:
+// one v_pk_fma_f32 whose two multiplicands are broadcast through op_sel, so the
+// operands are used where the 16-byte LDS reads left them (no register moves).
+template <int LH, int RH>
+__device__ __forceinline__ void pk_fma_bcast(float2v &acc, const float2v &lpair, const float2v &rpair)
 {
+    if constexpr (LH == 0 && RH == 0)
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "+v"(acc) : "v"(lpair), "v"(rpair));
+    else if constexpr (LH == 0 && RH == 1)
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(lpair), "v"(rpair));
+    else if constexpr (LH == 1 && RH == 0)
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(lpair), "v"(rpair));
+    else
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(lpair), "v"(rpair));
+}
+
+struct Quad {           // four consecutive pixels as two register pairs
+    float2v lo, hi;
+};
+
+template <bool ALIGNED>
+__device__ __forceinline__ Quad load_quad(const float *src)
+{
+    Quad q;
     if constexpr (ALIGNED) {
-        const float4 v = *reinterpret_cast<const float4 *>(src);
-        dst[0] = v.x;
-        dst[1] = v.y;
-        dst[2] = v.z;
-        dst[3] = v.w;
+        const float4v v = *reinterpret_cast<const float4v *>(src);
+        q.lo = v.xy;
+        q.hi = v.zw;
     } else {
-        dst[0] = src[0];
-        dst[1] = src[1];
-        dst[2] = src[2];
-        dst[3] = src[3];
+        q.lo = float2v{src[0], src[1]};
+        q.hi = float2v{src[2], src[3]};
+    }
+    return q;
+}
+
+template <int K>
+__device__ __forceinline__ const float2v &pair_of(const Quad *q)
+{
+    return (K & 2) ? q[K / 4].hi : q[K / 4].lo;
+}
+
+template <int K>
+__device__ __forceinline__ float elem_of(const Quad *q)
+{
+    const float2v &p = pair_of<K>(q);
+    return (K & 1) ? p.y : p.x;
+}
+
+// One left column u against the D right columns u .. u+D-1, for window pair P.
+template <int WIN_W, int D, int U, int P, int DD = 0>
+__device__ __forceinline__ void column_step(float2v (&acc)[BAND_X / 2][D], const Quad &lq, const Quad *rq)
+{
+    if constexpr (DD < D) {
+        constexpr bool lo = 2 * P <= U && U < 2 * P + WIN_W;          // window 2P covers column U
+        constexpr bool hi = 2 * P + 1 <= U && U < 2 * P + 1 + WIN_W;  // window 2P+1 covers it
+        constexpr int I = U & 3, K = U + DD;
+        const float2v &lp2 = (I & 2) ? lq.hi : lq.lo;
+        if constexpr (lo && hi) {
+            pk_fma_bcast<(I & 1), (K & 1)>(acc[P][DD], lp2, pair_of<K>(rq));
+        } else if constexpr (lo) {
+            acc[P][DD].x = fmaf((I & 1) ? lp2.y : lp2.x, elem_of<K>(rq), acc[P][DD].x);
+        } else if constexpr (hi) {
+            acc[P][DD].y = fmaf((I & 1) ? lp2.y : lp2.x, elem_of<K>(rq), acc[P][DD].y);
+        }
+        column_step<WIN_W, D, U, P, DD + 1>(acc, lq, rq);
     }
 }
 
-typedef float float2v __attribute__((ext_vector_type(2)));
+template <int WIN_W, int D, int C, int I = 0>
+__device__ __forceinline__ void quad_step(float2v (&acc)[BAND_X / 2][D], const Quad &lq, const Quad *rq)
+{
+    constexpr int NU = WIN_W + BAND_X - 1;
+    if constexpr (I < 4) {
+        constexpr int U = 4 * C + I;
+        if constexpr (U < NU) {
+            column_step<WIN_W, D, U, 0>(acc, lq, rq);
+            column_step<WIN_W, D, U, 1>(acc, lq, rq);
+        }
+        quad_step<WIN_W, D, C, I + 1>(acc, lq, rq);
+    }
+}
+
+template <int WIN_W, int D, bool ALIGNED, int C = 0>
+__device__ __forceinline__ void row_step(float2v (&acc)[BAND_X / 2][D], const float *lp, const float *rp,
+                                         const Quad &l_head, Quad *rq)
+{
+    constexpr int NU = WIN_W + BAND_X - 1;       // left columns touched by the lane's windows
+    constexpr int NCL = (NU + 3) / 4;            // ... in groups of four
+    constexpr int NCR = (NU + D - 1 + 3) / 4;    // right columns in groups of four
+    constexpr int AHEAD = (D + 2) / 4;           // right groups needed beyond group C
+    if constexpr (C < NCL) {
+        Quad lq;
+        if constexpr (C == 0)
+            lq = l_head;                         // prefetched during the previous row
+        else
+            lq = load_quad<true>(lp + 4 * C);
+        if constexpr (C + AHEAD < NCR && C + AHEAD >= AHEAD + (AHEAD == 0 ? 1 : 0))
+            rq[C + AHEAD] = load_quad<ALIGNED>(rp + 4 * (C + AHEAD));
+        quad_step<WIN_W, D, C>(acc, lq, rq);
+        row_step<WIN_W, D, ALIGNED, C + 1>(acc, lp, rp, l_head, rq);
+    }
+}
 
 // acc[p][d] = (window 2p, window 2p+1) at offset d:
 //   acc[x][d] += sum over `rows` image rows and the window's columns of
@@ -112,59 +202,40 @@ typedef float float2v __attribute__((ext_vector_type(2)));
 // lp / rp point at the lane's first left column / first right column (offset d = 0
 // of this pass) in the first row.  Two neighbouring windows share every product
 // except at their outer columns, so the bulk of the work is issued as packed
-// v_pk_fma_f32 with both multiplicands broadcast (op_sel), which lets a single
-// wavefront keep its SIMD's FMA pipe full; the outer columns use scalar FMAs.
+// v_pk_fma_f32 with both multiplicands broadcast, which lets a single wavefront
+// keep its SIMD's FMA pipe full; the outer columns use scalar FMAs.  The first
+// LDS reads of each row are issued during the previous row's arithmetic.
 template <int WIN_W, int D, bool ALIGNED>
 __device__ __forceinline__ void accumulate(const float *__restrict__ lp, const float *__restrict__ rp,
                                            int lpitch, int rpitch, int rows,
                                            float2v (&acc)[BAND_X / 2][D])
 {
-    constexpr int NU = WIN_W + BAND_X - 1;       // left columns touched by the lane's windows
-    constexpr int NCL = (NU + 3) / 4;            // ... in groups of four
-    constexpr int NCR = (NU + D - 1 + 3) / 4;    // right columns in groups of four
-    constexpr int AHEAD = (D + 2) / 4;           // right groups needed beyond group c
+    constexpr int NU = WIN_W + BAND_X - 1;
+    constexpr int NCR = (NU + D - 1 + 3) / 4;
+    constexpr int AHEAD = (D + 2) / 4;
+    constexpr int HEAD = AHEAD == 0 ? 1 : AHEAD;   // right quads needed before the first FMA
+    Quad l_head = load_quad<true>(lp);
+    Quad r_head[HEAD];
+#pragma unroll
+    for (int c = 0; c < HEAD; ++c)
+        r_head[c] = load_quad<ALIGNED>(rp + 4 * c);
 #pragma unroll 1
     for (int a = 0; a < rows; ++a) {
-        float rv[NCR * 4];
+        Quad rq[NCR];
 #pragma unroll
-        for (int c = 0; c < AHEAD && c < NCR; ++c)
-            load4<ALIGNED>(rv + 4 * c, rp + 4 * c);
+        for (int c = 0; c < HEAD; ++c)
+            rq[c] = r_head[c];
+        const Quad l_cur = l_head;
+        // next row's head (the last iteration re-reads its own row: no read past the tile)
+        const float *lnext = a + 1 < rows ? lp + lpitch : lp;
+        const float *rnext = a + 1 < rows ? rp + rpitch : rp;
+        l_head = load_quad<true>(lnext);
 #pragma unroll
-        for (int c = 0; c < NCL; ++c) {
-            float lv[4];
-            load4<true>(lv, lp + 4 * c);
-            if (c + AHEAD < NCR)
-                load4<ALIGNED>(rv + 4 * (c + AHEAD), rp + 4 * (c + AHEAD));
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int u = 4 * c + i;
-                if (u < NU) {
-#pragma unroll
-                    for (int p = 0; p < BAND_X / 2; ++p) {
-                        const bool lo = 2 * p <= u && u < 2 * p + WIN_W;          // window 2p
-                        const bool hi = 2 * p + 1 <= u && u < 2 * p + 1 + WIN_W;  // window 2p+1
-                        if (lo && hi) {
-                            const float2v l2 = {lv[i], lv[i]};
-#pragma unroll
-                            for (int d = 0; d < D; ++d) {
-                                const float2v r2 = {rv[u + d], rv[u + d]};
-                                acc[p][d] = __builtin_elementwise_fma(l2, r2, acc[p][d]);
-                            }
-                        } else if (lo) {
-#pragma unroll
-                            for (int d = 0; d < D; ++d)
-                                acc[p][d].x = fmaf(lv[i], rv[u + d], acc[p][d].x);
-                        } else if (hi) {
-#pragma unroll
-                            for (int d = 0; d < D; ++d)
-                                acc[p][d].y = fmaf(lv[i], rv[u + d], acc[p][d].y);
-                        }
-                    }
-                }
-            }
-        }
-        lp += lpitch;
-        rp += rpitch;
+        for (int c = 0; c < HEAD; ++c)
+            r_head[c] = load_quad<ALIGNED>(rnext + 4 * c);
+        row_step<WIN_W, D, ALIGNED>(acc, lp, rp, l_cur, rq);
+        lp = lnext;
+        rp = rnext;
     }
 }
 
@@ -228,6 +299,49 @@ __device__ __forceinline__ void finish_pass(const BandGeom &g, const float2v (&a
     }
 }
 
+// Pace keeping between the wavefronts that share a SIMD.  The hardware issues
+// from the oldest ready wavefront first, so without intervention the four
+// wavefronts of a SIMD run one after the other, and the last one ends up alone on
+// the SIMD - where a single wavefront cannot keep the packed-FMA pipe full.  Each
+// wavefront therefore publishes how many passes it has finished and lowers its own
+// issue priority by its lead over the slowest wavefront of its SIMD, which keeps
+// all four within a pass or two of each other until the end of the tile.
+// Wavefronts w, w+4, w+8, ... of a workgroup share a SIMD.
+__device__ __forceinline__ void keep_pace(volatile int *progress, int wave, int done)
+{
+    progress[wave] = done;
+    int slowest = done;
+#pragma unroll
+    for (int m = (wave & 3); m < BAND_WAVES; m += 4)
+        slowest = min(slowest, progress[m]);
+    const int lead = done - slowest;
+    if (lead <= 0)
+        __builtin_amdgcn_s_setprio(3);
+    else if (lead == 1)
+        __builtin_amdgcn_s_setprio(2);
+    else if (lead == 2)
+        __builtin_amdgcn_s_setprio(1);
+    else
+        __builtin_amdgcn_s_setprio(0);
+}
+
+// Diagnostic build only (-DSVAMD_BAND_STAMPS, see profiles/stamp_band.py): the
+// `scores` argument is reinterpreted as a buffer of 40 wall-clock stamps per
+// wavefront (kernel entry, then the end of every 8-offset pass) and no scores
+// are written.
+#ifdef SVAMD_BAND_STAMPS
+#define SV_STAMP(slot)                                                                           \
+    do {                                                                                         \
+        if (scores && lane == 0)                                                                 \
+            reinterpret_cast<long long *>(scores)[(((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * \
+                                                   BAND_WAVES + wave) * 40 + (slot)] = wall_clock64(); \
+    } while (0)
+#define SV_SCORES_OUT nullptr
+#else
+#define SV_STAMP(slot) do { } while (0)
+#define SV_SCORES_OUT scores
+#endif
+
 template <int WIN_W>
 __global__ void __launch_bounds__(BAND_THREADS)
 band_scan_kernel(BandGeom g, const uint8_t *__restrict__ left, const uint8_t *__restrict__ right,
@@ -236,6 +350,7 @@ band_scan_kernel(BandGeom g, const uint8_t *__restrict__ left, const uint8_t *__
                  int32_t *__restrict__ out_disp, double *__restrict__ out_val, double *__restrict__ scores)
 {
     extern __shared__ __align__(16) float tile[];
+    __shared__ int progress[BAND_WAVES];
     float *Lt = tile;
     float *Rt = tile + g.tile_rows * g.lpitch;
 
@@ -247,6 +362,11 @@ band_scan_kernel(BandGeom g, const uint8_t *__restrict__ left, const uint8_t *__
     const bool active = wave < g.tile_wrows && wy < g.row_end;  // wave-uniform
     const int xbase = x0 + BAND_X * lane;
     const int lrow = wave * g.stride_y;                       // tile row of this wave's first image row
+
+    if (lane == 0)
+        progress[wave] = active ? 0 : 0x7fffffff;   // idle wavefronts never hold anyone back
+    int passes = 0;
+    __builtin_amdgcn_s_setprio(3);                  // everyone starts level; leaders step down
 
     LaneState st;
 #pragma unroll
@@ -260,6 +380,7 @@ band_scan_kernel(BandGeom g, const uint8_t *__restrict__ left, const uint8_t *__
         st.arg[x] = g.mode == SVAMD_BAND_ARGMAX ? SVAMD_BAND_NO_MATCH : 0;
     }
 
+    SV_STAMP(0);
     stage_tile(left, g.H, g.W, y0, g.tile_rows, x0, g.lpitch, Lt);
     const float *lp = Lt + lrow * g.lpitch + BAND_X * lane;
 
@@ -287,15 +408,19 @@ band_scan_kernel(BandGeom g, const uint8_t *__restrict__ left, const uint8_t *__
         for (; k + BAND_D <= kend; k += BAND_D) {
             float2v acc[BAND_X / 2][BAND_D] = {};
             accumulate<WIN_W, BAND_D, true>(lp, rp + (k - k0), g.lpitch, g.rpitch, g.win_h, acc);
-            finish_pass<BAND_D>(g, acc, k, kend, false, wy, xbase, wsum_r, winv_r, st, scores);
+            finish_pass<BAND_D>(g, acc, k, kend, false, wy, xbase, wsum_r, winv_r, st, SV_SCORES_OUT);
+            keep_pace(progress, wave, ++passes);
+            SV_STAMP(1 + k / BAND_D);
         }
         for (; k < kend; ++k) {  // fewer than 8 offsets left in this chunk
             float2v acc[BAND_X / 2][1] = {};
             accumulate<WIN_W, 1, false>(lp, rp + (k - k0), g.lpitch, g.rpitch, g.win_h, acc);
-            finish_pass<1>(g, acc, k, kend, false, wy, xbase, wsum_r, winv_r, st, scores);
+            finish_pass<1>(g, acc, k, kend, false, wy, xbase, wsum_r, winv_r, st, SV_SCORES_OUT);
         }
     }
 
+    if (lane == 0)
+        progress[wave] = 0x7fffffff;
     if (active) {
 #pragma unroll
         for (int x = 0; x < BAND_X; ++x) {
