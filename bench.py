@@ -102,10 +102,17 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', 1))
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
-    torch.cuda.set_device(local_rank)
+    # SVAMD_BENCH_BACKEND=gloo rehearses the multi-process path on a box with fewer
+    # GPUs than ranks (ranks share devices, results travel through host memory)
+    backend = os.environ.get('SVAMD_BENCH_BACKEND', 'nccl')
+    device_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device_index)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', device_index))
+        else:
+            dist.init_process_group(backend)
 
     import band_scan as bs
 
@@ -117,10 +124,11 @@ def main():
 
     disp16 = torch.empty(scanner.disp.shape, dtype=torch.int16, device='cuda')
     val32 = torch.empty(scanner.val.shape, dtype=torch.float32, device='cuda')
+    wire = 'cuda' if backend == 'nccl' else 'cpu'
     gathered = None
     if world > 1 and rank == 0:
-        gathered = ([torch.empty_like(disp16) for _ in range(world)],
-                    [torch.empty_like(val32) for _ in range(world)])
+        gathered = ([torch.empty(disp16.shape, dtype=disp16.dtype, device=wire) for _ in range(world)],
+                    [torch.empty(val32.shape, dtype=val32.dtype, device=wire) for _ in range(world)])
 
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
@@ -135,8 +143,8 @@ def main():
         if world > 1:                                       # results -> rank 0 over RCCL
             disp16.copy_(scanner.disp)
             val32.copy_(scanner.val)
-            dist.gather(disp16, gathered[0] if rank == 0 else None, dst=0)
-            dist.gather(val32, gathered[1] if rank == 0 else None, dst=0)
+            dist.gather(disp16.to(wire), gathered[0] if rank == 0 else None, dst=0)
+            dist.gather(val32.to(wire), gathered[1] if rank == 0 else None, dst=0)
 
     for _ in range(args.warmup):
         step()
@@ -153,7 +161,7 @@ def main():
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        t = torch.tensor([elapsed], dtype=torch.float64, device=wire)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

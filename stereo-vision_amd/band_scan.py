@@ -11,6 +11,7 @@ arg-max of utils.max_pos (utils.py:17-26) or image_scan's selection rule
 import numpy as np
 
 import _native as nv
+import sharding
 import sv_image_comparison as _svic
 
 WINDOW_WIDTHS = (7, 11, 15, 21, 31)    # widths the tuned kernel is compiled for
@@ -96,8 +97,18 @@ def band_scan(left_image, right_image, window_width, window_height, max_disparit
     scanner = BandScanner(left.shape[0], left.shape[1], window_width, window_height, max_disparity,
                           row_stride, want_scores)
     scanner.upload(left, right)
-    scanner.run(correlation_threshold)
-    out = (scanner.disp.cpu().numpy(), scanner.val.cpu().numpy())
+    rank, size = sharding.world()
+    if size == 1:
+        scanner.run(correlation_threshold)
+        out = (scanner.disp.cpu().numpy(), scanner.val.cpu().numpy())
+        if want_scores:
+            out += (scanner.scores.cpu().numpy(),)
+        return out
+    # one band of window rows per rank, then an all-gather of the results
+    begin, end = sharding.shard_range(scanner.nwy, rank, size)
+    scanner.run(correlation_threshold, rows=(begin, end))
+    out = (sharding.all_gather_concat(scanner.disp[begin:end].cpu().numpy(), scanner.nwy),
+           sharding.all_gather_concat(scanner.val[begin:end].cpu().numpy(), scanner.nwy))
     if want_scores:
-        out += (scanner.scores.cpu().numpy(),)
+        out += (sharding.all_gather_concat(scanner.scores[begin:end].cpu().numpy(), scanner.nwy),)
     return out

@@ -14,6 +14,7 @@ import correlation_spectral
 from correlation_spectral import cross_correlate_2d_spectral as x_corr_2d
 from utils import max_pos
 import _native as nv
+import sharding
 
 # Amount by which the correlation of a non-central region must exceed that of
 # the central one to register a displacement (reference sv_image_comparison.py:11)
@@ -155,6 +156,24 @@ def _batched_path_available():
 
 
 def _select(tbase, rbase, desc, is_centre, skip, win_off, threshold, max_side):
+    '''Pairs + selection rule for all windows of a stage.  With an initialised
+    torch.distributed process group of N ranks (one per GPU, both images resident
+    on each) every rank evaluates a contiguous 1/N of the windows and the
+    per-window results are all-gathered; otherwise everything runs locally.'''
+    win_off = np.asarray(win_off, dtype=np.int64)
+    nwin = len(win_off) - 1
+    rank, size = sharding.world()
+    if size == 1 or nwin < size:
+        return _select_local(tbase, rbase, desc, is_centre, skip, win_off, threshold, max_side)
+    begin, end = sharding.shard_range(nwin, rank, size)
+    p0, p1 = int(win_off[begin]), int(win_off[end])
+    best_pair, best_val = _select_local(tbase, rbase, desc[p0:p1], is_centre[p0:p1], skip[p0:p1],
+                                        win_off[begin:end + 1] - p0, threshold, max_side)
+    best_pair = np.where(best_pair >= 0, best_pair + p0, -1)
+    return sharding.all_gather_concat(best_pair, nwin), sharding.all_gather_concat(best_val, nwin)
+
+
+def _select_local(tbase, rbase, desc, is_centre, skip, win_off, threshold, max_side):
     '''Runs every pair and the selection rule on the GPU.  desc: P x 8 int64,
     win_off: nwin + 1 offsets.  Returns (best_pair, best_val) as numpy arrays.'''
     torch = nv.torch_cuda()
