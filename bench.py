@@ -122,13 +122,16 @@ def main():
     scanner.upload(left, right)
     evals = count_evals(H, W, WIN, MAX_DISP)
 
-    disp16 = torch.empty(scanner.disp.shape, dtype=torch.int16, device='cuda')
-    val32 = torch.empty(scanner.val.shape, dtype=torch.float32, device='cuda')
+    # results travel as one byte buffer per rank: int16 disparities then float32
+    # correlations (6 bytes per window; 16-bit integers are not a collective dtype)
+    nwin = scanner.disp.numel()
+    packed = torch.empty(6 * nwin, dtype=torch.uint8, device='cuda')
+    disp16 = packed[:2 * nwin].view(torch.int16).view(scanner.disp.shape)
+    val32 = packed[2 * nwin:].view(torch.float32).view(scanner.val.shape)
     wire = 'cuda' if backend == 'nccl' else 'cpu'
     gathered = None
     if world > 1 and rank == 0:
-        gathered = ([torch.empty(disp16.shape, dtype=disp16.dtype, device=wire) for _ in range(world)],
-                    [torch.empty(val32.shape, dtype=val32.dtype, device=wire) for _ in range(world)])
+        gathered = [torch.empty(6 * nwin, dtype=torch.uint8, device=wire) for _ in range(world)]
 
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
@@ -143,8 +146,7 @@ def main():
         if world > 1:                                       # results -> rank 0 over RCCL
             disp16.copy_(scanner.disp)
             val32.copy_(scanner.val)
-            dist.gather(disp16.to(wire), gathered[0] if rank == 0 else None, dst=0)
-            dist.gather(val32.to(wire), gathered[1] if rank == 0 else None, dst=0)
+            dist.gather(packed.to(wire), gathered, dst=0)
 
     for _ in range(args.warmup):
         step()
