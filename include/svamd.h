@@ -92,6 +92,21 @@ int svamd_cross_correlate_2d_spectral(const void *tmpl, int tmpl_dtype, int th, 
                                       double min_std, double min_mean_diff, double *out,
                                       void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- a2, batched, power-of-two shapes: the FFT route of correlation_spectral.py:51-54 --
+ * `batch` independent pairs: templates [batch][th][tw] and regions [batch][H][W],
+ * float32, H and W powers of two in 4..1024 (svamd_fft_supported).  Same
+ * semantics as svamd_cross_correlate_2d_spectral (statistics over the full
+ * arrays, template zero-padded or cropped top-left to H x W, low-deviation
+ * branch); evaluated by a radix-4 FFT in LDS: packed row transforms, column
+ * transforms fused with the conjugate multiply and the inverse column transform,
+ * inverse row transforms.  out: [batch][H][W] of out_dtype (SVAMD_F32 or
+ * SVAMD_F64). */
+int svamd_fft_supported(int H, int W);
+size_t svamd_xcorr2d_fft_workspace_bytes(int batch, int H, int W);
+int svamd_xcorr2d_fft(const float *tmpl, int th, int tw, const float *region, int H, int W,
+                      int batch, double min_std, double min_mean_diff, void *out, int out_dtype,
+                      void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- a3: cross_correlate_1d(vec_1, vec_2, normalised) -------------------------
  * correlation.py:44-75 (and its list twin cross_correlate_1d_raw, :4-42).
  * v1, v2: n float64.  out: 2n-1 float64. */

@@ -38,6 +38,9 @@ PROTOTYPES = {
     'svamd_cross_correlate_2d': (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     'svamd_cross_correlate_2d_spectral_workspace_bytes': (_sz, [_i, _i, _i, _i]),
     'svamd_cross_correlate_2d_spectral': (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _d, _d, _vp, _vp, _sz, _vp]),
+    'svamd_fft_supported': (_i, [_i, _i]),
+    'svamd_xcorr2d_fft_workspace_bytes': (_sz, [_i, _i, _i]),
+    'svamd_xcorr2d_fft': (_i, [_vp, _i, _i, _vp, _i, _i, _i, _d, _d, _vp, _i, _vp, _sz, _vp]),
     'svamd_cross_correlate_1d_workspace_bytes': (_sz, [_i64]),
     'svamd_cross_correlate_1d': (_i, [_vp, _vp, _i64, _i, _vp, _vp, _sz, _vp]),
     'svamd_cross_correlate_1d_spectral_workspace_bytes': (_sz, [_i64, _i64]),

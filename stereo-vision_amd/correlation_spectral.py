@@ -18,6 +18,11 @@ MIN_ST_DEV = 1e-4
 # (reference correlation_spectral.py:10)
 MIN_MEAN_DIFF = 1e-9
 
+# The float32 FFT route's rounding error grows with sqrt(region size / template
+# size); it is taken only when the (cropped) template covers at least 1/FFT_MIN_COVER
+# of the region, smaller templates go through the direct sliding kernel.
+FFT_MIN_COVER = 4
+
 
 def cross_correlate_1d_spectral(template: np.ndarray, signal: np.ndarray):
     '''Circular cross-correlation, length len(signal) + len(template) - 1, of the
@@ -55,6 +60,29 @@ def _small_pair_surface(template, region):
     return surf.cpu().numpy()
 
 
+def cross_correlate_2d_spectral_batched(templates, regions, out_dtype=np.float32):
+    '''`cross_correlate_2d_spectral` for a stack of pairs at once: templates
+    [B, th, tw] and regions [B, H, W] with H and W powers of two (4..1024),
+    through the batched LDS FFT kernels.  Returns [B, H, W] of out_dtype.  Inputs
+    are used as float32.'''
+    torch = nv.torch_cuda()
+    lib = nv.load_library()
+    t = np.ascontiguousarray(templates, dtype=np.float32)
+    r = np.ascontiguousarray(regions, dtype=np.float32)
+    batch, th, tw = t.shape
+    _, H, W = r.shape
+    if r.shape[0] != batch:
+        raise Exception('Numbers of templates and regions must match')
+    d_t, d_r = nv.to_device(t), nv.to_device(r)
+    f64 = np.dtype(out_dtype) == np.float64
+    out = nv.empty((batch, H, W), torch.float64 if f64 else torch.float32)
+    ws = nv.workspace(lib.svamd_xcorr2d_fft_workspace_bytes(batch, H, W))
+    nv.call('svamd_xcorr2d_fft', nv.ptr(d_t), th, tw, nv.ptr(d_r), H, W, batch, float(MIN_ST_DEV),
+            float(MIN_MEAN_DIFF), nv.ptr(out), nv.F64 if f64 else nv.F32, nv.ptr(ws), ws.numel(),
+            nv.stream_ptr())
+    return out.cpu().numpy()
+
+
 def cross_correlate_2d_spectral(orig_template: np.ndarray, orig_region: np.ndarray):
     '''Normalised circular cross-correlation surface of a template and a region,
     shape = region.shape; the template is zero-padded or cropped (top-left) to
@@ -67,6 +95,10 @@ def cross_correlate_2d_spectral(orig_template: np.ndarray, orig_region: np.ndarr
     rh, rw = region.shape
     if max(th, tw, rh, rw) <= nv.PAIR_MAX_SIDE and min(th, tw, rh, rw) > 0:
         return _small_pair_surface(template, region)
+    overlap = min(th, rh) * min(tw, rw)
+    if overlap * FFT_MIN_COVER >= rh * rw and nv.load_library().svamd_fft_supported(rh, rw):
+        # power-of-two region: batched LDS FFT route with a batch of one
+        return cross_correlate_2d_spectral_batched(template[None], region[None], np.float64)[0]
 
     torch = nv.torch_cuda()
     t = nv.as_image(template)

@@ -382,3 +382,48 @@ def test_band_scan_rejects_unsupported(mods):
         b.band_scan(np.random.default_rng(0).random((40, 40)), np.zeros((40, 40)), 7, 7, 3)
     with pytest.raises(mods['n'].NativeError, match='no compiled kernel'):
         b.band_scan(np.zeros((40, 40), np.uint8), np.zeros((40, 40), np.uint8), 8, 8, 3)
+
+
+# ---- FFT route (power-of-two shapes) ------------------------------------------------
+def test_fft_route_golden_rand_pairs(mods):
+    for n in (256, 1024):
+        g = golden(f'g4_spectral_rand{n}')
+        t, r, idx = rand_pair(n)
+        out = mods['s'].cross_correlate_2d_spectral(t, r)
+        assert out.dtype == np.float64 and out.shape == (n, n)
+        assert_surface_close(out.ravel()[idx], g['sample_val'], SURFACE_TOL, f'rand{n}')
+        assert int(np.argmax(out)) == int(g['argmax'])
+        assert abs(out.max() - float(g['max_val'])) < SURFACE_TOL
+
+
+@pytest.mark.parametrize('tshape,rshape', [((128, 128), (128, 128)), ((64, 256), (64, 256)),
+                                           ((128, 32), (128, 32)), ((100, 190), (128, 256)), ((40, 70), (128, 256)),
+                                           ((300, 200), (256, 128)), ((100, 8), (8, 512))])
+def test_fft_route_vs_oracle(mods, oracle, tshape, rshape):
+    rng = np.random.default_rng(sum(tshape) + sum(rshape))
+    t = rng.random(tshape).astype(np.float32)
+    r = (rng.random(rshape) * 255).astype(np.float32)
+    got = mods['s'].cross_correlate_2d_spectral(t, r)
+    want = oracle.cross_correlate_2d_spectral_fft(t.astype(np.float64), r.astype(np.float64))
+    assert_surface_close(got, want, SURFACE_TOL, f'fft {tshape} vs {rshape}')
+    assert int(np.argmax(got)) == int(np.argmax(want))
+
+
+def test_fft_route_batched_and_branches(mods, oracle):
+    rng = np.random.default_rng(99)
+    t = rng.random((5, 128, 128)).astype(np.float32)
+    r = rng.random((5, 128, 128)).astype(np.float32)
+    t[1] = 0.5                       # homogeneous template, different mean -> zeros
+    t[2] = 0.25
+    r[2] = 0.25                      # homogeneous template, same mean -> ones
+    r[3] = 0.75                      # constant region -> NaN
+    r[4] = np.roll(t[4], (5, 9), axis=(0, 1))
+    out = mods['s'].cross_correlate_2d_spectral_batched(t, r)
+    assert out.dtype == np.float32 and out.shape == (5, 128, 128)
+    want0 = oracle.cross_correlate_2d_spectral_fft(t[0].astype(np.float64), r[0].astype(np.float64))
+    assert_surface_close(out[0], want0, SURFACE_TOL, 'batch[0]')
+    assert np.all(out[1] == 0.0)
+    assert np.all(out[2] == 1.0)
+    assert np.isnan(out[3]).all()
+    assert np.unravel_index(np.argmax(out[4]), out[4].shape) == (5, 9)
+    assert abs(out[4].max() - 1.0) < SURFACE_TOL
