@@ -1,0 +1,165 @@
+#!/usr/bin/env python3
+'''Secondary measurements: the other BASELINE configs (the headline config is
+bench.py's).  Prints one JSON line per measurement.  GPU times are wall clock of
+the host-level call (upload + kernels + download) unless marked "device".
+
+  config 1  spatial cross_correlate_2d, NaN-masked 123x111 template and a
+            135x136 template over a 433x862 uint8 region, steps 5 and 1
+  config 2  1D cross-correlation, n = 44000, spatial and spectral
+  config 3  sequence_scan with the portal scan config (12x12 windows, 11x1
+            scheme) on the 560x790 cone pair and on a synthetic 960x1080 pair
+  config 5  batched 1024x1024 circular NCC through the LDS FFT, B = 8 and 64
+'''
+import contextlib
+import io
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'stereo-vision_amd'))
+sys.path.insert(0, ROOT)
+
+import torch                     # noqa: E402
+import _native as nv             # noqa: E402
+import correlation               # noqa: E402
+import correlation_spectral      # noqa: E402
+import sv_image_comparison       # noqa: E402
+
+PORTAL = [{'window_width': 12, 'window_height': 12, 'scheme': [11, 1], 'scheme_shift_size': [1, 0],
+           'window_overlap': 0, 'correlation_threshold': 0.93}]
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def timed(fn, *a, repeat=3, **k):
+    best = None
+    for _ in range(repeat):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = quiet(fn, *a, **k)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return best, out
+
+
+def emit(**kw):
+    print(json.dumps(kw), flush=True)
+
+
+def config1():
+    rng = np.random.default_rng(1)
+    region = rng.integers(0, 256, size=(433, 862), dtype=np.uint8)
+    masked = rng.integers(0, 256, size=(123, 111)).astype(np.float64)
+    masked[rng.random(masked.shape) < 0.7] = np.nan
+    full = region[150:285, 290:426].astype(np.float64)
+    for name, tmpl in (('123x111 NaN-masked', masked), ('135x136', full)):
+        for step in (5, 1):
+            dt, out = timed(correlation.cross_correlate_2d, tmpl, region, step, step)
+            emit(config=1, what=f'cross_correlate_2d {name} template, 433x862 uint8 region, step {step}',
+                 seconds=dt, evals=out.size, evals_per_s=out.size / dt,
+                 gflops=2 * tmpl.size * out.size / dt / 1e9)
+
+
+def config2():
+    rng = np.random.default_rng(0)
+    n = 44000
+    s1 = rng.standard_normal(n)
+    s2 = np.roll(s1, 137) + 0.1 * rng.standard_normal(n)
+    dt, out = timed(correlation.cross_correlate_1d, s1, s2)
+    emit(config=2, what='cross_correlate_1d n=44000 (2n-1 lags)', seconds=dt, argmax=int(np.argmax(out)),
+         lags_per_s=out.size / dt, gflops=2 * n * out.size / dt / 1e9)
+    dt, out = timed(correlation_spectral.cross_correlate_1d_spectral, s1, s2)
+    emit(config=2, what='cross_correlate_1d_spectral n=44000', seconds=dt, argmax=int(np.argmax(out)),
+         lags_per_s=out.size / dt)
+    t0 = time.perf_counter()
+    np.correlate(s2 - s2.mean(), s1 - s1.mean(), mode='full')
+    emit(config=2, what='cpu numpy.correlate(full) of the same signals (1 thread)',
+         seconds=time.perf_counter() - t0)
+
+
+def scan_counts(res):
+    pairs = sum(len(w['target_regions']) for w in res[0].values())
+    moved = sum(1 for w in res[0].values() if w['dp_x'] or w['dp_y'])
+    return len(res[0]), pairs, moved
+
+
+def config3():
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'g6_cone_images.npz'))
+    left, right = g['left'] / 255.0, g['right'] / 255.0
+    dt, res = timed(sv_image_comparison.sequence_scan, left, right, PORTAL)
+    nwin, pairs, moved = scan_counts(res)
+    emit(config=3, what='sequence_scan portal config, cone 560x790', seconds=dt, windows=nwin, pairs=pairs,
+         nonzero=moved, pairs_per_s=pairs / dt, surface_elems_per_s=pairs * 144 / dt)
+    import bench
+    l, r = bench.synthetic_pair(1080, 960, 5)
+    dt, res = timed(sv_image_comparison.sequence_scan, l / 255.0, r / 255.0, PORTAL, repeat=2)
+    nwin, pairs, moved = scan_counts(res)
+    emit(config=3, what='sequence_scan portal config, synthetic 960x1080', seconds=dt, windows=nwin,
+         pairs=pairs, nonzero=moved, pairs_per_s=pairs / dt, surface_elems_per_s=pairs * 144 / dt)
+    # device-only time of the pair kernel for the cone scan
+    windows, tb, rb = sv_image_comparison._stage0_windows(left, right, 12, 12, (11, 1), (1, 0), 0)
+    batch = sv_image_comparison._StageBatch(left.shape[1], right.shape[1])
+    for (wid, w), t, rbx in zip(windows.items(), tb, rb):
+        batch.add(t, w['centre'], w['target_regions'], rbx)
+    desc = nv.to_device(np.concatenate(batch.desc))
+    dl, dr = nv.to_device(left), nv.to_device(right)
+    out = nv.empty(desc.shape[0], torch.float64)
+    for precision, tag in ((nv.ACC_F32, 'f32'), (nv.ACC_F64, 'f64')):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for it in range(3):
+            if it == 2:
+                e0.record()
+            nv.call('svamd_scan_pairs', nv.ptr(dl), nv.ptr(dr), nv.ptr(desc), desc.shape[0], 12, 1e-4, 1e-9,
+                    precision, nv.ptr(out), None, None, None, nv.stream_ptr())
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1)
+        emit(config=3, what=f'svamd_scan_pairs ({tag}) device time, cone portal pairs', device_ms=ms,
+             pairs=int(desc.shape[0]), pairs_per_s=desc.shape[0] / ms * 1e3)
+
+
+def config5():
+    lib = nv.load_library()
+    n = 1024
+    for batch in (8, 64):
+        g = torch.Generator(device='cuda').manual_seed(0)
+        t = torch.rand((batch, n, n), generator=g, device='cuda', dtype=torch.float32)
+        r = torch.rand((batch, n, n), generator=g, device='cuda', dtype=torch.float32)
+        out = torch.empty((batch, n, n), device='cuda', dtype=torch.float32)
+        ws = nv.workspace(lib.svamd_xcorr2d_fft_workspace_bytes(batch, n, n))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 5
+        for it in range(reps + 1):
+            if it == 1:
+                e0.record()
+            nv.call('svamd_xcorr2d_fft', nv.ptr(t), n, n, nv.ptr(r), n, n, batch, 1e-4, 1e-9, nv.ptr(out),
+                    nv.F32, nv.ptr(ws), ws.numel(), nv.stream_ptr())
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        pairs_per_s = batch / ms * 1e3
+        emit(config=5, what=f'svamd_xcorr2d_fft batch {batch} of 1024x1024 float32 pairs, device time',
+             device_ms=ms, pairs_per_s=pairs_per_s, surface_elems_per_s=pairs_per_s * n * n,
+             algorithmic_GBps=pairs_per_s * 12.6e6 / 1e9, hbm_frac_of_8TBps=pairs_per_s * 12.6e6 / 8e12)
+    # CPU: scipy/numpy FFT of one pair, the reference's own route (1 thread)
+    from oracle import ncc_oracle
+    a = np.random.default_rng(0).random((n, n))
+    b = np.random.default_rng(1).random((n, n))
+    t0 = time.perf_counter()
+    ncc_oracle.cross_correlate_2d_spectral_fft(a, b)
+    emit(config=5, what='cpu numpy FFT route, one 1024x1024 float64 pair (1 thread)',
+         seconds=time.perf_counter() - t0)
+
+
+if __name__ == '__main__':
+    which = sys.argv[1:] or ['1', '2', '3', '5']
+    for c in which:
+        {'1': config1, '2': config2, '3': config3, '5': config5}[c]()

@@ -28,9 +28,19 @@ constexpr int FFT_MAX_N = 1024;
 constexpr int FFT_COLS = 8;          // spectrum columns per tile in pass 2
 constexpr int FFT_THREADS = 256;
 
-struct FftStats {                    // per pair, accumulated with float64 atomics
-    double t_sum, t_sq, r_sum, r_sq;
+struct FftStats {                    // per pair
+    double t_sum, t_sq, r_sum, r_sq;  // sums of (x - centre), (x - centre)^2 (float64 atomics)
+    float t_centre, r_centre;         // constants subtracted before the transforms
+    float pad[2];
 };
+
+// Mean and population standard deviation from sums of (x - c) and (x - c)^2.
+__device__ __forceinline__ void moments(double sum, double sq, double n, double c, double &mean, double &var)
+{
+    const double m = sum / n;
+    mean = c + m;
+    var = sq / n - m * m;
+}
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b)
 {
@@ -182,7 +192,7 @@ fft_stats_kernel(const float *__restrict__ t, int64_t t_elems, const float *__re
 }
 
 // ---- pass 1: packed row transform ---------------------------------------------------
-// One workgroup per (row, pair).  spec_t / spec_r: [pair][H][hp] complex, hp = W/2 + 8.
+// One workgroup per (row, pair).  spec_t / spec_r: [pair][H][hp] complex, hp = W/2 + 16.
 __global__ void __launch_bounds__(FFT_THREADS)
 fft_rows_forward_kernel(const float *__restrict__ t, int th, int tw_, const float *__restrict__ r, int H,
                         int W, int log2w, const FftStats *__restrict__ stats,
@@ -317,6 +327,473 @@ fft_rows_inverse_kernel(const float2 *__restrict__ spec, int th, int tw_, int H,
     }
 }
 
+// =====================================================================================
+// 1024-point fast path: one wavefront per transform, 16 elements per lane.
+//
+// The in-place radix-4 schedule above is kept (same positions, same digit-reversed
+// output), but the five stages are grouped so that consecutive stages find their
+// four operands inside one lane: lanes first hold positions lane + 64 m (stages
+// of length 1024 and 256), then 64 B + s + 4 m with B = lane / 4, s = lane % 4
+// (lengths 64 and 16), then 4 (lane + 64 u) + e (length 4).  Only two exchanges
+// through LDS per transform, no workgroup barrier: a wavefront's LDS operations
+// execute in order.  LDS positions are padded by 4 elements per 64 so that the
+// strided accesses of the exchanges fall on distinct banks.
+// =====================================================================================
+constexpr int F1K = 1024;
+constexpr int F1K_LDS = F1K + 4 * (F1K / 64);     // padded elements per sequence
+
+__device__ __forceinline__ int f1k_idx(int p) { return p + 4 * (p >> 6); }
+
+__device__ __forceinline__ void dif4(float2 &a, float2 &b, float2 &c, float2 &d, float2 w1, float2 w2, float2 w3)
+{
+    const float2 apc = cadd(a, c), amc = csub(a, c), bpd = cadd(b, d), bmd = csub(b, d);
+    a = cadd(apc, bpd);
+    b = cmul(cadd(amc, mul_mi(bmd)), w1);
+    c = cmul(csub(apc, bpd), w2);
+    d = cmul(cadd(amc, mul_pi(bmd)), w3);
+}
+__device__ __forceinline__ void dif4_plain(float2 &a, float2 &b, float2 &c, float2 &d)
+{
+    const float2 apc = cadd(a, c), amc = csub(a, c), bpd = cadd(b, d), bmd = csub(b, d);
+    a = cadd(apc, bpd);
+    b = cadd(amc, mul_mi(bmd));
+    c = csub(apc, bpd);
+    d = cadd(amc, mul_pi(bmd));
+}
+__device__ __forceinline__ void dit4(float2 &a, float2 &b, float2 &c, float2 &d, float2 w1, float2 w2, float2 w3)
+{
+    b = cmul_conj(b, w1);
+    c = cmul_conj(c, w2);
+    d = cmul_conj(d, w3);
+    const float2 apc = cadd(a, c), amc = csub(a, c), bpd = cadd(b, d), bmd = csub(b, d);
+    a = cadd(apc, bpd);
+    b = cadd(amc, mul_pi(bmd));
+    c = csub(apc, bpd);
+    d = cadd(amc, mul_mi(bmd));
+}
+__device__ __forceinline__ void dit4_plain(float2 &a, float2 &b, float2 &c, float2 &d)
+{
+    const float2 apc = cadd(a, c), amc = csub(a, c), bpd = cadd(b, d), bmd = csub(b, d);
+    a = cadd(apc, bpd);
+    b = cadd(amc, mul_pi(bmd));
+    c = csub(apc, bpd);
+    d = cadd(amc, mul_mi(bmd));
+}
+
+// Forward transform.  In: v[m] = position lane + 64 m (natural order).  Out:
+// v[4 u + e] = position 4 (lane + 64 u) + e of the digit-reversed spectrum.
+// x: this wavefront's LDS region (F1K_LDS elements); tw: exp(-2 pi i k / 1024).
+__device__ __forceinline__ void f1k_forward(float2 (&v)[16], float2 *x, const float2 *__restrict__ tw, int lane)
+{
+#pragma unroll
+    for (int m0 = 0; m0 < 4; ++m0) {               // length 1024
+        const int j = lane + 64 * m0;
+        dif4(v[m0], v[m0 + 4], v[m0 + 8], v[m0 + 12], tw[j], tw[2 * j], tw[3 * j]);
+    }
+    {
+        const float2 w1 = tw[4 * lane], w2 = tw[8 * lane], w3 = tw[12 * lane];   // length 256
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            dif4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3], w1, w2, w3);
+    }
+#pragma unroll
+    for (int m = 0; m < 16; ++m)
+        x[f1k_idx(lane + 64 * m)] = v[m];
+    __builtin_amdgcn_wave_barrier();
+    const int blk = lane >> 2, s = lane & 3;
+#pragma unroll
+    for (int m = 0; m < 16; ++m)
+        v[m] = x[f1k_idx(64 * blk + s + 4 * m)];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int m0 = 0; m0 < 4; ++m0) {               // length 64
+        const int j = s + 4 * m0;
+        dif4(v[m0], v[m0 + 4], v[m0 + 8], v[m0 + 12], tw[16 * j], tw[32 * j], tw[48 * j]);
+    }
+    {
+        const float2 w1 = tw[64 * s], w2 = tw[128 * s], w3 = tw[192 * s];        // length 16
+#pragma unroll
+        for (int h = 0; h < 4; ++h)
+            dif4(v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3], w1, w2, w3);
+    }
+#pragma unroll
+    for (int m = 0; m < 16; ++m)
+        x[f1k_idx(64 * blk + s + 4 * m)] = v[m];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            v[4 * u + e] = x[f1k_idx(4 * (lane + 64 * u) + e)];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int u = 0; u < 4; ++u)                    // length 4
+        dif4_plain(v[4 * u], v[4 * u + 1], v[4 * u + 2], v[4 * u + 3]);
+}
+
+// Inverse transform (unscaled).  In: v[4 u + e] = digit-reversed position
+// 4 (lane + 64 u) + e.  Out: v[m] = natural position lane + 64 m.
+__device__ __forceinline__ void f1k_inverse(float2 (&v)[16], float2 *x, const float2 *__restrict__ tw, int lane)
+{
+#pragma unroll
+    for (int u = 0; u < 4; ++u)                    // length 4
+        dit4_plain(v[4 * u], v[4 * u + 1], v[4 * u + 2], v[4 * u + 3]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            x[f1k_idx(4 * (lane + 64 * u) + e)] = v[4 * u + e];
+    __builtin_amdgcn_wave_barrier();
+    const int blk = lane >> 2, s = lane & 3;
+#pragma unroll
+    for (int m = 0; m < 16; ++m)
+        v[m] = x[f1k_idx(64 * blk + s + 4 * m)];
+    __builtin_amdgcn_wave_barrier();
+    {
+        const float2 w1 = tw[64 * s], w2 = tw[128 * s], w3 = tw[192 * s];        // length 16
+#pragma unroll
+        for (int h = 0; h < 4; ++h)
+            dit4(v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3], w1, w2, w3);
+    }
+#pragma unroll
+    for (int m0 = 0; m0 < 4; ++m0) {               // length 64
+        const int j = s + 4 * m0;
+        dit4(v[m0], v[m0 + 4], v[m0 + 8], v[m0 + 12], tw[16 * j], tw[32 * j], tw[48 * j]);
+    }
+#pragma unroll
+    for (int m = 0; m < 16; ++m)
+        x[f1k_idx(64 * blk + s + 4 * m)] = v[m];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int m = 0; m < 16; ++m)
+        v[m] = x[f1k_idx(lane + 64 * m)];
+    __builtin_amdgcn_wave_barrier();
+    {
+        const float2 w1 = tw[4 * lane], w2 = tw[8 * lane], w3 = tw[12 * lane];   // length 256
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            dit4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3], w1, w2, w3);
+    }
+#pragma unroll
+    for (int m0 = 0; m0 < 4; ++m0) {               // length 1024
+        const int j = lane + 64 * m0;
+        dit4(v[m0], v[m0 + 4], v[m0 + 8], v[m0 + 12], tw[j], tw[2 * j], tw[3 * j]);
+    }
+}
+
+// Constants subtracted from the arrays before the float32 transforms, which keeps
+// a large DC term out of the butterflies.  A full-size array only needs an
+// approximate centre (the mean of its first row): the exact mean differs from it
+// by a constant, i.e. only in the DC bin, which pass 2 clears.  A template that is
+// zero-padded or cropped needs its exact mean (a constant inside a window is not a
+// pure DC term).  One workgroup per pair.
+__global__ void __launch_bounds__(1024)
+fft_centres_kernel(const float *__restrict__ t, int th, int tw_, const float *__restrict__ r, int H, int W,
+                   FftStats *__restrict__ stats)
+{
+    __shared__ double red[17];
+    const int pair = blockIdx.x;
+    const float *tp = t + (int64_t)pair * th * tw_;
+    const float *rp = r + (int64_t)pair * H * W;
+    const bool exact_t = th != H || tw_ != W;
+    const int64_t tcount = exact_t ? (int64_t)th * tw_ : tw_;
+    double ts = 0.0, rs = 0.0;
+    for (int64_t i = threadIdx.x; i < tcount; i += blockDim.x)
+        ts += tp[i];
+    for (int i = threadIdx.x; i < W; i += blockDim.x)
+        rs += rp[i];
+    ts = block_sum(ts, red);
+    rs = block_sum(rs, red);
+    if (threadIdx.x == 0) {
+        FftStats st;
+        st.t_sum = st.t_sq = st.r_sum = st.r_sq = 0.0;
+        st.t_centre = (float)(ts / (double)tcount);
+        st.r_centre = (float)(rs / (double)W);
+        st.pad[0] = st.pad[1] = 0.f;
+        stats[pair] = st;
+    }
+}
+
+// Adds the per-row partial sums of pass 1 into the pair's statistics (fixed order:
+// results do not depend on scheduling).  One workgroup per pair.
+__global__ void __launch_bounds__(1024)
+fft_row_sums_kernel(const double *__restrict__ row_sums, int H, FftStats *__restrict__ stats)
+{
+    __shared__ double red[17];
+    const int pair = blockIdx.x;
+    double a = 0, b = 0, c = 0, d = 0;
+    for (int y = threadIdx.x; y < H; y += blockDim.x) {
+        const double4 v = reinterpret_cast<const double4 *>(row_sums)[(int64_t)pair * H + y];
+        a += v.x;
+        b += v.y;
+        c += v.z;
+        d += v.w;
+    }
+    a = block_sum(a, red);
+    b = block_sum(b, red);
+    c = block_sum(c, red);
+    d = block_sum(d, red);
+    if (threadIdx.x == 0) {
+        stats[pair].t_sum = a;
+        stats[pair].t_sq = b;
+        stats[pair].r_sum = c;
+        stats[pair].r_sq = d;
+    }
+}
+
+// pass 1, W = 1024: one wavefront per image row, four rows per workgroup.  Also
+// produces each row's exact sums of (x - centre) and (x - centre)^2 of both arrays.
+__global__ void __launch_bounds__(256)
+f1k_rows_forward_kernel(const float *__restrict__ t, int th, int tw_, const float *__restrict__ r, int H,
+                        const FftStats *__restrict__ stats, double *__restrict__ row_sums,
+                        const float2 *__restrict__ twiddle, float2 *__restrict__ spec_t,
+                        float2 *__restrict__ spec_r, int hp)
+{
+    __shared__ float2 lds[4 * F1K_LDS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int y = blockIdx.x * 4 + wave, pair = blockIdx.y;
+    if (y >= H)
+        return;
+    float2 *x = lds + wave * F1K_LDS;
+    const float *tbase = t + (int64_t)pair * th * tw_;
+    const float *rbase = r + (int64_t)pair * H * F1K;
+    const float tc = stats[pair].t_centre, rc = stats[pair].r_centre;
+    const float *trow = tbase + (int64_t)y * tw_;
+    const float *rrow = rbase + (int64_t)y * F1K;
+    const bool trow_in = y < min(th, H);
+    const int mw = min(tw_, F1K);
+    float2 v[16];
+    // per-lane partial sums of 16 centred values fit float32 comfortably; lanes and
+    // rows are combined in float64
+    float fts = 0.f, ftq = 0.f, frs = 0.f, frq = 0.f;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+        const int xx = lane + 64 * m;
+        const float tv = (trow_in && xx < mw) ? trow[xx] - tc : 0.0f;
+        const float rv = rrow[xx] - rc;
+        v[m] = make_float2(tv, rv);
+        fts += tv;
+        ftq = fmaf(tv, tv, ftq);
+        frs += rv;
+        frq = fmaf(rv, rv, frq);
+    }
+    double ts = fts, tq = ftq, rs = frs, rq = frq;
+    // template statistics cover the whole template: add what the crop to the
+    // region's shape left out (columns beyond W, rows beyond H)
+    for (int yy = y; yy < th; yy += H)
+        for (int xx = (yy == y && trow_in ? mw : 0) + lane; xx < tw_; xx += 64) {
+            const double d = (double)(tbase[(int64_t)yy * tw_ + xx] - tc);
+            ts += d;
+            tq += d * d;
+        }
+    ts = wave_sum(ts);
+    tq = wave_sum(tq);
+    rs = wave_sum(rs);
+    rq = wave_sum(rq);
+    if (lane == 0)                  // per-row partial sums; fft_row_sums_kernel adds them up
+        reinterpret_cast<double4 *>(row_sums)[(int64_t)pair * H + y] = make_double4(ts, tq, rs, rq);
+    f1k_forward(v, x, twiddle, lane);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            x[f1k_idx(4 * (lane + 64 * u) + e)] = v[4 * u + e];
+    __builtin_amdgcn_wave_barrier();
+    float2 *ot = spec_t + ((int64_t)pair * H + y) * hp;
+    float2 *orr = spec_r + ((int64_t)pair * H + y) * hp;
+#pragma unroll
+    for (int i = 0; i <= 8; ++i) {
+        const int k = lane + 64 * i;
+        if (k <= F1K / 2) {
+            const float2 zk = x[f1k_idx(digit_reverse(k, 10))];
+            const float2 zm = x[f1k_idx(digit_reverse((F1K - k) & (F1K - 1), 10))];
+            ot[k] = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
+            orr[k] = make_float2(0.5f * (zk.y + zm.y), 0.5f * (zm.x - zk.x));
+        }
+    }
+}
+
+// pass 2, H = 1024: a tile of 8 spectrum columns; wavefront c transforms column c of
+// T (kept in registers), then column c of R, multiplies and transforms back.  The
+// R tile is fetched into registers before the T transform starts, so its memory
+// latency is covered by arithmetic.
+constexpr int F1K_TILE = 8;
+constexpr int F1K_COL = F1K_LDS + 2;              // column stride in LDS (bank spread for the transpose)
+constexpr int F1K_QUADS = F1K * (F1K_TILE / 2) / (64 * F1K_TILE);   // 16-byte pieces per lane and tile
+
+__device__ __forceinline__ void f1k_tile_fetch(const float2 *__restrict__ g, int hp, int c0, int ncols,
+                                               float4 (&q)[F1K_QUADS])
+{
+#pragma unroll
+    for (int n = 0; n < F1K_QUADS; ++n) {
+        const int i = threadIdx.x + n * 64 * F1K_TILE;
+        const int y = i / (F1K_TILE / 2), cp = (i % (F1K_TILE / 2)) * 2;
+        q[n] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c0 + cp + 1 < ncols) {
+            q[n] = *reinterpret_cast<const float4 *>(g + (int64_t)y * hp + c0 + cp);
+        } else if (c0 + cp < ncols) {
+            const float2 a = g[(int64_t)y * hp + c0 + cp];
+            q[n].x = a.x;
+            q[n].y = a.y;
+        }
+    }
+}
+
+// [y][8 columns] pieces -> [column][y] in LDS
+__device__ __forceinline__ void f1k_tile_scatter(const float4 (&q)[F1K_QUADS], float2 *tile)
+{
+#pragma unroll
+    for (int n = 0; n < F1K_QUADS; ++n) {
+        const int i = threadIdx.x + n * 64 * F1K_TILE;
+        const int y = i / (F1K_TILE / 2), cp = (i % (F1K_TILE / 2)) * 2;
+        tile[cp * F1K_COL + f1k_idx(y)] = make_float2(q[n].x, q[n].y);
+        tile[(cp + 1) * F1K_COL + f1k_idx(y)] = make_float2(q[n].z, q[n].w);
+    }
+}
+
+// Persistent workgroups: each loops over (pair, tile) work items and always has the
+// next tile's memory reads in flight while it transforms the current one.
+// 8 wavefronts of up to 256 registers per lane: one workgroup per CU (the transform
+// of T stays in registers while R is transformed, and a tile prefetch is in flight)
+__global__ void __launch_bounds__(64 * F1K_TILE)
+f1k_cols_fused_kernel(float2 *__restrict__ spec_t, const float2 *__restrict__ spec_r, int ncols, int hp,
+                      int tiles_per_pair, int total_tiles, const float2 *__restrict__ twiddle)
+{
+    __shared__ float2 tile[F1K_TILE * F1K_COL];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float2 *x = tile + wave * F1K_COL;
+    // Two neighbouring tiles share every 128-byte line of a spectrum row.  Workgroups
+    // b and b + 8 run on the same XCD (round-robin dispatch), so they are given
+    // neighbouring work items: the second one finds the lines in that XCD's L2.
+    int first = blockIdx.x;
+    if (first < (int)(gridDim.x & ~15u))
+        first = (first & ~15) + ((first & 7) << 1) + ((first >> 3) & 1);
+
+    float4 q[F1K_QUADS];
+    int item = first;
+    if (item < total_tiles) {
+        const int pair = item / tiles_per_pair, c0 = (item % tiles_per_pair) * F1K_TILE;
+        f1k_tile_fetch(spec_t + (int64_t)pair * F1K * hp, hp, c0, ncols, q);
+    }
+    for (; item < total_tiles; item += gridDim.x) {
+        const int pair = item / tiles_per_pair, c0 = (item % tiles_per_pair) * F1K_TILE;
+        float2 *gt = spec_t + (int64_t)pair * F1K * hp;
+        const float2 *gr = spec_r + (int64_t)pair * F1K * hp;
+        f1k_tile_scatter(q, tile);                     // T tile
+        f1k_tile_fetch(gr, hp, c0, ncols, q);          // R tile: in flight during the T transform
+        __syncthreads();
+        float2 tv[16], v[16];
+#pragma unroll
+        for (int m = 0; m < 16; ++m)
+            tv[m] = x[f1k_idx(lane + 64 * m)];
+        __builtin_amdgcn_wave_barrier();
+        f1k_forward(tv, x, twiddle, lane);
+        __syncthreads();
+        f1k_tile_scatter(q, tile);                     // R tile
+        const int next = item + gridDim.x;
+        if (next < total_tiles) {                      // next T tile: in flight during the rest
+            const int npair = next / tiles_per_pair, nc0 = (next % tiles_per_pair) * F1K_TILE;
+            f1k_tile_fetch(spec_t + (int64_t)npair * F1K * hp, hp, nc0, ncols, q);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < 16; ++m)
+            v[m] = x[f1k_idx(lane + 64 * m)];
+        __builtin_amdgcn_wave_barrier();
+        f1k_forward(v, x, twiddle, lane);
+#pragma unroll
+        for (int m = 0; m < 16; ++m)
+            v[m] = cmul_conj(v[m], tv[m]);             // conj(T) * R, position by position
+        // the arrays were centred only approximately: removing their exact means is the
+        // same as clearing the DC bin (position 0 of spectrum column 0)
+        if (c0 + wave == 0 && lane == 0)
+            v[0] = make_float2(0.f, 0.f);
+        f1k_inverse(v, x, twiddle, lane);
+#pragma unroll
+        for (int m = 0; m < 16; ++m)
+            x[f1k_idx(lane + 64 * m)] = v[m];
+        __syncthreads();
+#pragma unroll
+        for (int n = 0; n < F1K_QUADS; ++n) {
+            const int i = threadIdx.x + n * 64 * F1K_TILE;
+            const int y = i / (F1K_TILE / 2), cp = (i % (F1K_TILE / 2)) * 2;
+            const float2 a = tile[cp * F1K_COL + f1k_idx(y)], b = tile[(cp + 1) * F1K_COL + f1k_idx(y)];
+            if (c0 + cp + 1 < ncols)
+                *reinterpret_cast<float4 *>(gt + (int64_t)y * hp + c0 + cp) = make_float4(a.x, a.y, b.x, b.y);
+            else if (c0 + cp < ncols)
+                gt[(int64_t)y * hp + c0 + cp] = a;
+        }
+        __syncthreads();                               // LDS is rewritten by the next item
+    }
+}
+
+// pass 3, W = 1024: one wavefront per two output rows, four wavefronts per workgroup
+template <typename TOut>
+__global__ void __launch_bounds__(256)
+f1k_rows_inverse_kernel(const float2 *__restrict__ spec, const float *__restrict__ t, int th, int tw_,
+                        const float *__restrict__ r, int H, int hp, const FftStats *__restrict__ stats,
+                        double min_std, double min_mean_diff, const float2 *__restrict__ twiddle,
+                        TOut *__restrict__ out)
+{
+    __shared__ float2 lds[4 * F1K_LDS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int y0 = 2 * (blockIdx.x * 4 + wave), pair = blockIdx.y;
+    if (y0 >= H)
+        return;
+    (void)t;
+    (void)r;
+    float2 *x = lds + wave * F1K_LDS;
+    const FftStats st = stats[pair];
+    const double tn = (double)th * tw_, rn = (double)H * F1K;
+    const double tc = st.t_centre, rc = st.r_centre;
+    double tmean, rmean, tvar, rvar;
+    moments(st.t_sum, st.t_sq, tn, tc, tmean, tvar);
+    moments(st.r_sum, st.r_sq, rn, rc, rmean, rvar);
+    const double tstd = sqrt(fmax(tvar, 0.0));
+    const double rstd = rvar > 1e-14 * (st.r_sq / rn + 1e-300) ? sqrt(rvar) : 0.0;
+    TOut *o0 = out + ((int64_t)pair * H + y0) * F1K;
+    TOut *o1 = o0 + F1K;
+    const bool second = y0 + 1 < H;
+    if (tstd < min_std || rstd == 0.0) {
+        const TOut fill = tstd < min_std ? (fabs(tmean - rmean) < min_mean_diff ? TOut(1) : TOut(0))
+                                         : TOut(NAN);
+        for (int xx = lane; xx < F1K; xx += 64) {
+            o0[xx] = fill;
+            if (second)
+                o1[xx] = fill;
+        }
+        return;
+    }
+    const float2 *p0 = spec + ((int64_t)pair * H + y0) * hp;
+    const float2 *p1 = second ? p0 + hp : p0;
+#pragma unroll
+    for (int i = 0; i <= 8; ++i) {
+        const int k = lane + 64 * i;
+        if (k <= F1K / 2) {
+            const float2 a = p0[k], b = p1[k];
+            x[f1k_idx(digit_reverse(k, 10))] = make_float2(a.x - b.y, a.y + b.x);          // a + i b
+            if (k > 0 && k < F1K / 2)       // Hermitian completion: conj(a) + i conj(b)
+                x[f1k_idx(digit_reverse(F1K - k, 10))] = make_float2(a.x + b.y, b.x - a.y);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    float2 v[16];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            v[4 * u + e] = x[f1k_idx(4 * (lane + 64 * u) + e)];
+    __builtin_amdgcn_wave_barrier();
+    f1k_inverse(v, x, twiddle, lane);
+    const float scale = (float)(1.0 / ((double)H * (double)F1K) / (tstd * tn) / rstd);
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+        o0[lane + 64 * m] = (TOut)(v[m].x * scale);
+        if (second)
+            o1[lane + 64 * m] = (TOut)(v[m].y * scale);
+    }
+}
+
 inline int ilog2(int v)
 {
     int l = 0;
@@ -339,9 +816,10 @@ extern "C" size_t svamd_xcorr2d_fft_workspace_bytes(int batch, int H, int W)
 {
     if (batch <= 0 || !svamd_fft_supported(H, W))
         return 0;
-    const size_t hp = (size_t)W / 2 + 8;
+    const size_t hp = (size_t)W / 2 + 16;
     return align_up((size_t)batch * sizeof(FftStats), 256) + 2 * align_up(FFT_MAX_N * sizeof(float2), 256) +
-           2 * align_up((size_t)batch * H * hp * sizeof(float2), 256);
+           2 * align_up((size_t)batch * H * hp * sizeof(float2), 256) +
+           align_up((size_t)batch * H * 4 * sizeof(double), 256);
 }
 
 extern "C" int svamd_xcorr2d_fft(const float *tmpl, int th, int tw, const float *region, int H, int W,
@@ -358,7 +836,7 @@ extern "C" int svamd_xcorr2d_fft(const float *tmpl, int th, int tw, const float 
                    workspace_bytes >= svamd_xcorr2d_fft_workspace_bytes(batch, H, W),
                SVAMD_ERR_WORKSPACE, "xcorr2d_fft: workspace missing, misaligned or too small");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int hp = W / 2 + 8, ncols = W / 2 + 1;
+    const int hp = W / 2 + 16, ncols = W / 2 + 1;   // row pitch: an odd number of 128-byte lines for W = 1024
     const int log2w = ilog2(W), log2h = ilog2(H);
     Carver ws(workspace);
     FftStats *stats = ws.take<FftStats>((size_t)batch);
@@ -366,17 +844,48 @@ extern "C" int svamd_xcorr2d_fft(const float *tmpl, int th, int tw, const float 
     float2 *tw_h = ws.take<float2>(FFT_MAX_N);
     float2 *spec_t = ws.take<float2>((size_t)batch * H * hp);
     float2 *spec_r = ws.take<float2>((size_t)batch * H * hp);
+    double *row_sums = ws.take<double>((size_t)batch * H * 4);
 
     SV_HIP(hipMemsetAsync(stats, 0, (size_t)batch * sizeof(FftStats), st));
     hipLaunchKernelGGL(twiddle_kernel, dim3((W + 255) / 256), dim3(256), 0, st, tw_w, W);
     SV_LAUNCH_CHECK();
     hipLaunchKernelGGL(twiddle_kernel, dim3((H + 255) / 256), dim3(256), 0, st, tw_h, H);
     SV_LAUNCH_CHECK();
-    const int64_t t_elems = (int64_t)th * tw, r_elems = (int64_t)H * W;
-    const int sblocks = (int)std::min<int64_t>(64, (r_elems + 4095) / 4096);
-    hipLaunchKernelGGL(fft_stats_kernel, dim3(sblocks, batch), dim3(256), 0, st, tmpl, t_elems, region, r_elems,
-                       stats);
-    SV_LAUNCH_CHECK();
+    const bool fast = H == F1K && W == F1K;   // wavefront-per-transform kernels
+    if (fast) {
+        hipLaunchKernelGGL(fft_centres_kernel, dim3(batch), dim3(1024), 0, st, tmpl, th, tw, region, H, W, stats);
+        SV_LAUNCH_CHECK();
+    }
+    if (!fast) {
+        const int64_t t_elems = (int64_t)th * tw, r_elems = (int64_t)H * W;
+        const int sblocks = (int)std::min<int64_t>(64, (r_elems + 4095) / 4096);
+        hipLaunchKernelGGL(fft_stats_kernel, dim3(sblocks, batch), dim3(256), 0, st, tmpl, t_elems, region,
+                           r_elems, stats);
+        SV_LAUNCH_CHECK();
+    }
+    if (fast) {
+        hipLaunchKernelGGL(f1k_rows_forward_kernel, dim3(H / 4, batch), dim3(256), 0, st, tmpl, th, tw, region, H,
+                           stats, row_sums, tw_w, spec_t, spec_r, hp);
+        SV_LAUNCH_CHECK();
+        hipLaunchKernelGGL(fft_row_sums_kernel, dim3(batch), dim3(1024), 0, st, row_sums, H, stats);
+        SV_LAUNCH_CHECK();
+        const int tiles_per_pair = (ncols + F1K_TILE - 1) / F1K_TILE;
+        const int total_tiles = tiles_per_pair * batch;
+        const int resident = 256;                 // one workgroup per CU (register-limited)
+        hipLaunchKernelGGL(f1k_cols_fused_kernel, dim3(total_tiles < resident ? total_tiles : resident),
+                           dim3(64 * F1K_TILE), 0, st, spec_t, spec_r, ncols, hp, tiles_per_pair, total_tiles,
+                           tw_h);
+        SV_LAUNCH_CHECK();
+        dim3 gf((H / 2 + 3) / 4, batch);
+        if (out_dtype == SVAMD_F32)
+            hipLaunchKernelGGL((f1k_rows_inverse_kernel<float>), gf, dim3(256), 0, st, spec_t, tmpl, th, tw,
+                               region, H, hp, stats, min_std, min_mean_diff, tw_w, static_cast<float *>(out));
+        else
+            hipLaunchKernelGGL((f1k_rows_inverse_kernel<double>), gf, dim3(256), 0, st, spec_t, tmpl, th, tw,
+                               region, H, hp, stats, min_std, min_mean_diff, tw_w, static_cast<double *>(out));
+        SV_LAUNCH_CHECK();
+        return SVAMD_OK;
+    }
     hipLaunchKernelGGL(fft_rows_forward_kernel, dim3(H, batch), dim3(FFT_THREADS), 0, st, tmpl, th, tw, region,
                        H, W, log2w, stats, tw_w, spec_t, spec_r, hp);
     SV_LAUNCH_CHECK();

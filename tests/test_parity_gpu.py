@@ -427,3 +427,17 @@ def test_fft_route_batched_and_branches(mods, oracle):
     assert np.isnan(out[3]).all()
     assert np.unravel_index(np.argmax(out[4]), out[4].shape) == (5, 9)
     assert abs(out[4].max() - 1.0) < SURFACE_TOL
+
+
+def test_fft_route_1024_shapes_and_offsets(mods, oracle):
+    '''1024 x 1024 fast path: large DC offset, template smaller / larger than the
+    region (zero-padding, cropping with full-template statistics).'''
+    rng = np.random.default_rng(1024)
+    r = (rng.random((1024, 1024)) * 40 + 180).astype(np.float32)        # mean >> deviation
+    for tshape in ((1024, 1024), (700, 900), (1100, 1030)):
+        t = (rng.random(tshape) * 40 + 100).astype(np.float32)
+        if tshape == (1024, 1024):
+            t[:, :] += np.linspace(0, 60, 1024, dtype=np.float32)[:, None]   # first row unrepresentative
+        got = mods['s'].cross_correlate_2d_spectral(t, r)
+        want = oracle.cross_correlate_2d_spectral_fft(t.astype(np.float64), r.astype(np.float64))
+        assert_surface_close(got, want, SURFACE_TOL, f'fft1024 {tshape}')
