@@ -109,7 +109,7 @@ def config3():
     batch = sv_image_comparison._StageBatch(left.shape[1], right.shape[1])
     for (wid, w), t, rbx in zip(windows.items(), tb, rb):
         batch.add(t, w['centre'], w['target_regions'], rbx)
-    desc = nv.to_device(np.concatenate(batch.desc))
+    desc = nv.to_device(batch.desc())
     dl, dr = nv.to_device(left), nv.to_device(right)
     out = nv.empty(desc.shape[0], torch.float64)
     for precision, tag in ((nv.ACC_F32, 'f32'), (nv.ACC_F64, 'f64')):

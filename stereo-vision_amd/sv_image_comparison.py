@@ -88,40 +88,88 @@ def _regions_for(centres, x_window, y_window, region_image):
     return regions, boxes
 
 
+def _axis_candidates(starts, window, span_hw, count, limit):
+    '''Along one image axis, for every window start: the candidate centres
+    (np.linspace, exactly as region_pairs builds them), their clipped integer
+    [begin, end) and whether get_window_boundaries would reject them.'''
+    centres = starts + window / 2
+    grid = np.linspace(centres - span_hw, centres + span_hw, count, axis=-1)        # [n, count]
+    half = window / 2
+    rejected = (grid + half <= 0) | (grid - half > limit)
+    begin = np.maximum(grid - half, 0).astype(np.int64)      # int() truncation of a value >= 0
+    end = np.minimum(grid + half, limit).astype(np.int64)
+    own_begin = np.maximum(centres - half, 0).astype(np.int64)
+    own_end = np.minimum(centres + half, limit).astype(np.int64)
+    own_rejected = (centres + half <= 0) | (centres - half > limit)
+    return dict(centres=centres.tolist(), grid=grid.tolist(), rejected=rejected.tolist(),
+                begin=begin.tolist(), end=end.tolist(), own_begin=own_begin.tolist(),
+                own_end=own_end.tolist(), own_rejected=own_rejected.tolist())
+
+
 def _stage0_windows(template_image, region_image, x_window, y_window, scheme, scheme_shift_size,
                     window_overlap):
     '''Windows of the first stage plus, per window, the template box and the
-    region boxes (x_start, x_end, y_start, y_end).'''
+    region boxes (x_start, x_end, y_start, y_end).  Same enumeration as the
+    reference's double loop with region_pairs / get_window_boundaries per window,
+    but the candidate grids and their clipping are computed once per window
+    column and once per window row.'''
     image_height, image_width = region_image.shape
     if template_image.shape[0] != image_height or template_image.shape[1] != image_width:
         raise Exception('Dimensions of template and region images must match')
+    if scheme[0] % 2 != 1 or scheme[1] % 2 != 1:
+        raise Exception('Scheme dimensions must be odd.')
     x_stride = int(x_window * (1 - window_overlap))
     y_stride = int(y_window * (1 - window_overlap))
+    if x_stride <= 0 or y_stride <= 0:
+        raise ValueError('window_overlap leaves a window stride of zero pixels')
+    x_span_hw = (scheme_shift_size[0] if scheme_shift_size[0] else x_window) * (scheme[0] - 1) / 2
+    y_span_hw = (scheme_shift_size[1] if scheme_shift_size[1] else y_window) * (scheme[1] - 1) / 2
+    xs = np.arange(0, image_width, x_stride)
+    ys = np.arange(0, image_height, y_stride)
+    ax = _axis_candidates(xs, x_window, x_span_hw, scheme[0], image_width)
+    ay = _axis_candidates(ys, y_window, y_span_hw, scheme[1], image_height)
+    size = (x_window, y_window)
+
     windows, template_boxes, region_boxes = {}, [], []
     window_id = 0
-    y = row = 0
-    while y < image_height:
-        x = column = 0
-        while x < image_width:
-            centre = (x + x_window / 2, y + y_window / 2)
-            regions, boxes = _regions_for(
-                region_pairs(centre[0], x_window, centre[1], y_window, scheme, scheme_shift_size),
-                x_window, y_window, region_image)
+    for row, y in enumerate(ys.tolist()):
+        y_centre = ay['centres'][row]
+        y_grid, y_rej = ay['grid'][row], ay['rejected'][row]
+        y_begin, y_end = ay['begin'][row], ay['end'][row]
+        for column, x in enumerate(xs.tolist()):
+            x_centre = ax['centres'][column]
+            x_grid, x_rej = ax['grid'][column], ax['rejected'][column]
+            x_begin, x_end = ax['begin'][column], ax['end'][column]
+            centre = (x_centre, y_centre)
+            regions, boxes = [], []
+            # the window's own position first, then the scheme grid row by row
+            if not (ax['own_rejected'][column] or ay['own_rejected'][row]):
+                x0, x1 = ax['own_begin'][column], ax['own_end'][column]
+                y0, y1 = ay['own_begin'][row], ay['own_end'][row]
+                regions.append({'centre': centre, 'size': (x1 - x0, y1 - y0),
+                                'image_slice': region_image[y0:y1, x0:x1]})
+                boxes.append((x0, x1, y0, y1))
+            for j, _y in enumerate(y_grid):
+                at_row = _y == y_centre
+                y0, y1 = y_begin[j], y_end[j]
+                for i, _x in enumerate(x_grid):
+                    if (at_row and _x == x_centre) or x_rej[i] or y_rej[j]:
+                        continue
+                    x0, x1 = x_begin[i], x_end[i]
+                    regions.append({'centre': (_x, _y), 'size': (x1 - x0, y1 - y0),
+                                    'image_slice': region_image[y0:y1, x0:x1]})
+                    boxes.append((x0, x1, y0, y1))
             windows[window_id] = {
                 'row': row,
                 'column': column,
                 'centre': centre,
-                'size': (x_window, y_window),
+                'size': size,
                 'image_slice': template_image[y:y + y_window, x:x + x_window],
                 'target_regions': regions,
             }
             template_boxes.append((x, min(x + x_window, image_width), y, min(y + y_window, image_height)))
             region_boxes.append(boxes)
             window_id += 1
-            x += x_stride
-            column += 1
-        y += y_stride
-        row += 1
     return windows, template_boxes, region_boxes
 
 
@@ -318,45 +366,47 @@ def image_scan(window_info, window_id, corr_threshold=0):
     return pos, val
 
 
-def _box_desc(template_box, region_boxes, width_t, width_r):
-    '''Descriptor rows {t_off, t_pitch, t_h, t_w, r_off, r_pitch, r_h, r_w} of one
-    template box against several region boxes, all inside the two images.'''
-    tx0, tx1, ty0, ty1 = template_box
-    rows = np.empty((len(region_boxes), 8), dtype=np.int64)
-    if len(region_boxes):
-        rb = np.asarray(region_boxes, dtype=np.int64).reshape(-1, 4)
-        rows[:, 0] = ty0 * width_t + tx0
-        rows[:, 1] = width_t
-        rows[:, 2] = ty1 - ty0
-        rows[:, 3] = tx1 - tx0
-        rows[:, 4] = rb[:, 2] * width_r + rb[:, 0]
-        rows[:, 5] = width_r
-        rows[:, 6] = rb[:, 3] - rb[:, 2]
-        rows[:, 7] = rb[:, 1] - rb[:, 0]
-    return rows
-
-
 class _StageBatch:
     '''Accumulates the (template, regions) groups of one stage for a single
-    pair of launches.'''
+    pair of launches; descriptor rows {t_off, t_pitch, t_h, t_w, r_off, r_pitch,
+    r_h, r_w} are built in one vectorised step.'''
 
     def __init__(self, width_t, width_r):
         self.width_t, self.width_r = width_t, width_r
-        self.desc, self.centre, self.offsets = [], [], [0]
+        self.template_boxes, self.region_boxes, self.centre, self.offsets = [], [], [], [0]
+        self._desc = None
 
     def add(self, template_box, centre, regions, region_boxes):
-        self.desc.append(_box_desc(template_box, region_boxes, self.width_t, self.width_r))
-        self.centre.append(np.fromiter((r['centre'] == centre for r in regions), dtype=bool,
-                                       count=len(regions)))
+        self.template_boxes.append(template_box)
+        self.region_boxes.extend(region_boxes)
+        self.centre.extend(r['centre'] == centre for r in regions)
         self.offsets.append(self.offsets[-1] + len(regions))
+        self._desc = None
+
+    def desc(self):
+        if self._desc is None:
+            tb = np.asarray(self.template_boxes, dtype=np.int64).reshape(-1, 4)
+            rb = np.asarray(self.region_boxes, dtype=np.int64).reshape(-1, 4)
+            tb = np.repeat(tb, np.diff(self.offsets), axis=0)
+            d = np.empty((len(rb), 8), dtype=np.int64)
+            d[:, 0] = tb[:, 2] * self.width_t + tb[:, 0]
+            d[:, 1] = self.width_t
+            d[:, 2] = tb[:, 3] - tb[:, 2]
+            d[:, 3] = tb[:, 1] - tb[:, 0]
+            d[:, 4] = rb[:, 2] * self.width_r + rb[:, 0]
+            d[:, 5] = self.width_r
+            d[:, 6] = rb[:, 3] - rb[:, 2]
+            d[:, 7] = rb[:, 1] - rb[:, 0]
+            self._desc = d
+        return self._desc
 
     def max_side(self):
-        d = np.concatenate(self.desc) if self.desc else np.zeros((0, 8), np.int64)
+        d = self.desc()
         return int(d[:, [2, 3, 6, 7]].max()) if len(d) else 0
 
     def run(self, left_dev, right_dev, threshold):
-        desc = np.concatenate(self.desc) if self.desc else np.zeros((0, 8), np.int64)
-        centre = np.concatenate(self.centre) if self.centre else np.zeros(0, bool)
+        desc = self.desc()
+        centre = np.asarray(self.centre, dtype=bool)
         skip = (desc[:, 6] <= 0) | (desc[:, 7] <= 0)
         return _select(left_dev, right_dev, desc, centre, skip, np.asarray(self.offsets),
                        threshold, max(self.max_side(), 1))

@@ -52,3 +52,35 @@ def assert_surface_close(got, want, tol=1e-5, what=''):
     if err.size:
         worst = np.max(err / bound)
         assert worst <= 1.0, f'{what}: max err {err.max():.3e} exceeds {tol} relative (x{worst:.2f})'
+
+
+def oracle_select_local(tbase, rbase, desc, is_centre, skip, win_off, threshold, max_side):
+    '''Stand-in for the device path with the same contract, built on the oracle.'''
+    import ctypes
+    from oracle import ncc_oracle as orc
+    import sv_image_comparison as v
+    lib = orc.lib()
+    left, right = tbase, rbase          # numpy arrays in this test
+    d = np.ascontiguousarray(desc, dtype=np.int64)
+    corr = np.full(len(d), np.nan)
+    for p, (to, tp, th, tw, ro, rp, rh, rw) in enumerate(d):
+        if rh <= 0 or rw <= 0:
+            continue
+        ty, tx = divmod(int(to), int(tp))
+        ry, rx = divmod(int(ro), int(rp))
+        corr[p] = orc.cross_correlate_2d_spectral(left[ty:ty + th, tx:tx + tw],
+                                                  right[ry:ry + rh, rx:rx + rw], want='max')
+    nwin = len(win_off) - 1
+    best_pair = np.empty(nwin, dtype=np.int64)
+    best_val = np.empty(nwin)
+    c_u8 = ctypes.POINTER(ctypes.c_uint8)
+    c_i64 = ctypes.POINTER(ctypes.c_int64)
+    c_d = ctypes.POINTER(ctypes.c_double)
+    cen = np.ascontiguousarray(is_centre, dtype=np.uint8)
+    skp = np.ascontiguousarray(skip, dtype=np.uint8)
+    off = np.ascontiguousarray(win_off, dtype=np.int64)
+    lib.orc_scan_fold(corr.ctypes.data_as(c_d), cen.ctypes.data_as(c_u8), skp.ctypes.data_as(c_u8),
+                      off.ctypes.data_as(c_i64), ctypes.c_long(nwin), ctypes.c_double(threshold),
+                      ctypes.c_double(v.CENTRE_TOL), best_pair.ctypes.data_as(c_i64),
+                      best_val.ctypes.data_as(c_d))
+    return best_pair, best_val

@@ -1,0 +1,89 @@
+'''Host side of the stereo scan on the CPU: window / region enumeration, batching
+into pair descriptors, stage hand-over and result assembly of
+sv_image_comparison.sequence_scan, with the device call replaced by the CPU
+oracle (same contract).  Compared against the reference's own outputs (golden
+vectors), so this pins everything but the kernels.'''
+import contextlib
+import io
+import json
+
+import numpy as np
+import pytest
+
+from helpers import golden, oracle_select_local
+
+
+@pytest.fixture()
+def host_only(monkeypatch, oracle):
+    import _native as nv
+    import sv_image_comparison as v
+    monkeypatch.setattr(v, '_select_local', oracle_select_local)
+    monkeypatch.setattr(nv, 'to_device', lambda a: np.ascontiguousarray(a))
+    return v
+
+
+def run_and_compare(v, g, left, right):
+    cfg = json.loads(str(g['config']))
+    for s in range(int(g['n_seq'])):
+        with contextlib.redirect_stdout(io.StringIO()):
+            res = v.sequence_scan(left, right, cfg[s])
+        for st, windows in enumerate(res):
+            want = g[f'seq{s}_stage{st}_windows']
+            centres = g[f'seq{s}_stage{st}_centres']
+            sizes = g[f'seq{s}_stage{st}_sizes']
+            assert list(windows) == [int(i) for i in want[:, 0]]
+            for i, w in enumerate(windows.values()):
+                row = want[i]
+                assert (w['row'], w['column']) == (int(row[1]), int(row[2]))
+                assert w['centre'] == (row[3], row[4])
+                assert (w['dp_x'], w['dp_y']) == (row[5], row[6]), (s, st, i)
+                assert len(w['target_regions']) == int(row[9])
+                assert [tuple(c) for c in w['stage_centres']] == [tuple(c) for c in centres[i, :int(row[7])]]
+                assert [tuple(z) for z in w['stage_sizes']] == [tuple(z) for z in sizes[i, :int(row[8])]]
+
+
+@pytest.mark.parametrize('name', ['g6_cone_scan_config_portal', 'g6_cone_scan_config', 'g9_cone_multipass'])
+def test_cone_scans_host_logic(host_only, name):
+    im = golden('g6_cone_images')
+    run_and_compare(host_only, golden(name), im['left'] / 255.0, im['right'] / 255.0)
+
+
+def test_window_dicts_match_reference_layout(host_only):
+    v = host_only
+    rng = np.random.default_rng(0)
+    left, right = rng.random((30, 50)), rng.random((30, 50))
+    windows = v.whole_image_search_regions(left, right, 12, 10, scheme=(3, 3), scheme_shift_size=(4, 0),
+                                           window_overlap=0.5)
+    assert list(windows) == list(range(len(windows)))
+    w = windows[0]
+    assert set(w) == {'row', 'column', 'centre', 'size', 'image_slice', 'target_regions'}
+    assert w['centre'] == (6.0, 5.0) and w['size'] == (12, 10)
+    assert w['image_slice'].base is left or w['image_slice'].base is left.base
+    # centre first, then the grid row by row without the centre
+    centres = [r['centre'] for r in w['target_regions']]
+    assert centres[0] == (6.0, 5.0)
+    assert centres[1:] == [c for c in v.region_pairs(6.0, 12, 5.0, 10, (3, 3), (4, 0))[1:]
+                           if v.get_window_boundaries(c[0], c[1], 12, 10, 50, 30) is not None]
+    for r in w['target_regions']:
+        b = v.get_window_boundaries(r['centre'][0], r['centre'][1], 12, 10, 50, 30)
+        assert r['size'] == (b[1] - b[0], b[3] - b[2])
+        assert np.shares_memory(r['image_slice'], right)
+        assert r['image_slice'].shape == (b[3] - b[2], b[1] - b[0])
+    # bottom-right windows are truncated by slicing
+    last = windows[len(windows) - 1]
+    assert last['image_slice'].shape[0] <= 10 and last['image_slice'].shape[1] <= 12
+
+
+def test_get_window_boundaries_edges(host_only):
+    v = host_only
+    assert v.get_window_boundaries(-6, 5, 12, 10, 50, 30) is None          # x + w/2 <= 0
+    assert v.get_window_boundaries(56.5, 5, 12, 10, 50, 30) is None        # x - w/2 > W
+    assert v.get_window_boundaries(56, 5, 12, 10, 50, 30) == (50, 50, 0, 10)   # starts exactly at W: empty
+    assert v.get_window_boundaries(3.5, 27.5, 12, 10, 50, 30) == (0, 9, 22, 30)
+    assert v.region_partition_pairs(10, 8, 6, 4, 2) == [(8.0, 5.0), (12.0, 5.0), (8.0, 7.0), (12.0, 7.0)]
+
+
+def test_zero_stride_is_rejected(host_only):
+    with pytest.raises(ValueError, match='stride of zero'):
+        host_only.whole_image_search_regions(np.zeros((40, 40)), np.zeros((40, 40)), 31, 31, (3, 1), (1, 0),
+                                             30 / 31)
