@@ -1,0 +1,126 @@
+'''Driver: runs every sequence of a scan config on a left/right image pair,
+accumulates the per-window displacements into full-resolution grids, averages
+them by the number of contributing windows and optionally saves / plots them.
+Counterpart of the reference's test_image_comparison.py with the same flags;
+--image_dir / --config_dir / --data_dir are additions.'''
+import json
+from argparse import ArgumentParser
+from datetime import datetime
+
+import numpy as np
+from PIL import Image
+
+from sv_image_comparison import sequence_scan, plot_sequence_output
+from utils import downsample
+
+
+def accumulate_sequence(seq_results, shape):
+    '''Paints dp_x, dp_y, |dp| and a contribution count over each window's box;
+    only the deepest stage a window reached contributes (reference
+    test_image_comparison.py:61-88).'''
+    image_height, image_width = shape
+    dp_x_grid, dp_y_grid = np.zeros(shape), np.zeros(shape)
+    depth_grid, contributions = np.zeros(shape), np.zeros(shape)
+    for stage, windows in enumerate(seq_results):
+        for window_info in windows.values():
+            reached = len(window_info['stage_centres']) - 1
+            if reached > stage:
+                continue
+            x, y = window_info['stage_centres'][stage - 1 if reached < stage else stage]
+            magnitude = np.sqrt(window_info['dp_x'] ** 2 + window_info['dp_y'] ** 2)
+            x_window, y_window = window_info['stage_sizes'][stage]
+            box = (slice(int(max(y - y_window / 2, 0)), int(min(y + y_window / 2, image_height))),
+                   slice(int(max(x - x_window / 2, 0)), int(min(x + x_window / 2, image_width))))
+            dp_x_grid[box] += window_info['dp_x']
+            dp_y_grid[box] += window_info['dp_y']
+            depth_grid[box] += magnitude
+            if magnitude > 0:
+                contributions[box] += 1
+    return depth_grid, dp_x_grid, dp_y_grid, contributions
+
+
+def calc_max_shift_magnitude(config):
+    spans = []
+    for axis, key in ((0, 'window_width'), (1, 'window_height')):
+        unit = config['scheme_shift_size'][axis] or config[key]
+        spans.append(unit * (config['scheme'][axis] - 1) / 2)
+    return np.sqrt(spans[0] ** 2 + spans[1] ** 2)
+
+
+def main():
+    parser = ArgumentParser()
+    parser.add_argument('--images', default='test_2_noise')
+    parser.add_argument('--ds_factor', type=int, default=1)
+    parser.add_argument('--config', default='scan_config.json')
+    parser.add_argument('--depth_output', default=None)
+    parser.add_argument('--depth_input', default=None)
+    parser.add_argument('--shift_plot_type', default='boxes')
+    parser.add_argument('--sequence_plots', action='store_true', default=False)
+    parser.add_argument('--hide_depth', action='store_true', default=False)
+    parser.add_argument('--image_dir', default='images-p2-uncal')
+    parser.add_argument('--config_dir', default='configs')
+    parser.add_argument('--data_dir', default='depth-data')
+    args = parser.parse_args()
+
+    with open(f'{args.config_dir}/{args.config}') as f:
+        config = json.load(f)
+
+    if args.depth_input is None:
+        images = []
+        for side in ('left', 'right'):
+            image = np.asarray(Image.open(f'{args.image_dir}/{side}_{args.images}.tiff').convert('L'))
+            images.append(downsample(image, args.ds_factor))
+        left_image, right_image = images
+        totals = [np.zeros(left_image.shape) for _ in range(4)]
+        for i, seq_config in enumerate(config):
+            start = datetime.now()
+            seq_results = sequence_scan(left_image, right_image, seq_config)
+            print(f'Time elapsed for sequence {i + 1} scan: {datetime.now() - start}')
+            if args.sequence_plots:
+                plot_sequence_output(left_image, right_image, seq_results,
+                                     max_shift_magnitude=calc_max_shift_magnitude(seq_config[0]),
+                                     shift_plot_type=args.shift_plot_type)
+            for total, grid in zip(totals, accumulate_sequence(seq_results, left_image.shape)):
+                total += grid
+        total_depth_grid, total_dp_x_grid, total_dp_y_grid, total_contributions_grid = totals
+        # average by the number of windows that contributed to each pixel
+        total_contributions_grid[total_contributions_grid == 0] = np.inf
+        total_depth_grid = total_depth_grid / total_contributions_grid
+        total_dp_x_grid = total_dp_x_grid / total_contributions_grid
+        total_dp_y_grid = total_dp_y_grid / total_contributions_grid
+        if args.depth_output is not None:
+            with open(f'{args.data_dir}/{args.depth_output}', 'w') as f:
+                json.dump({
+                    'depth_grid': total_depth_grid.tolist(),
+                    'dp_x_grid': total_dp_x_grid.tolist(),
+                    'dp_y_grid': total_dp_y_grid.tolist(),
+                    'contributions_grid': total_contributions_grid.tolist(),
+                }, f)
+            print(f'Data saved to file {args.depth_output}')
+        else:
+            print('No output file specified.')
+    else:
+        with open(f'{args.data_dir}/{args.depth_input}') as f:
+            saved = json.load(f)
+        total_depth_grid = np.array(saved['depth_grid'])
+        total_contributions_grid = np.array(saved['contributions_grid'])
+        print(f'Data read from file {args.depth_input}')
+
+    if not args.hide_depth:
+        from matplotlib import cm
+        from matplotlib import pyplot as plt
+        figure = plt.figure()
+        ax = figure.add_subplot(1, 1, 1, projection='3d')
+        x_grid, y_grid = np.meshgrid(range(total_depth_grid.shape[1]), range(total_depth_grid.shape[0]))
+        ax.set_ylim(total_depth_grid.shape[0], 0)
+        ax.plot_surface(x_grid, y_grid, total_depth_grid, cmap=cm.coolwarm)
+        ax.set_xlabel('x')
+        ax.set_ylabel('y')
+        figure = plt.figure()
+        figure.add_subplot(1, 2, 1).imshow(total_depth_grid)
+        figure.add_subplot(1, 2, 2).imshow(total_contributions_grid)
+        plt.show()
+
+
+if __name__ == '__main__':
+    main()

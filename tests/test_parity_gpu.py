@@ -441,3 +441,60 @@ def test_fft_route_1024_shapes_and_offsets(mods, oracle):
         got = mods['s'].cross_correlate_2d_spectral(t, r)
         want = oracle.cross_correlate_2d_spectral_fft(t.astype(np.float64), r.astype(np.float64))
         assert_surface_close(got, want, SURFACE_TOL, f'fft1024 {tshape}')
+
+
+# ---- driver scripts --------------------------------------------------------------------
+def run_driver(module, argv, monkeypatch, capsys):
+    import importlib
+    import sys
+    monkeypatch.setattr(sys, 'argv', [module] + argv)
+    mod = importlib.import_module(module)
+    mod.main()
+    return capsys.readouterr().out
+
+
+def test_driver_2d_xcorr(mods, tmp_path, monkeypatch, capsys):
+    from PIL import Image
+    g = golden('g1_spatial_template_region')
+    t = g['template']
+    rgba = np.zeros(t.shape + (4,), np.uint8)
+    grey = np.nan_to_num(t, nan=0).astype(np.uint8)
+    rgba[..., 0] = rgba[..., 1] = rgba[..., 2] = grey
+    rgba[..., 3] = np.where(np.isnan(t), 0, 255)
+    Image.fromarray(rgba, 'RGBA').save(tmp_path / 'template.PNG')
+    Image.fromarray(g['region'], 'L').save(tmp_path / 'region.PNG')
+    out = run_driver('test_2d_xcorr', ['--template', 'template.PNG', '--region', 'region.PNG', '--step', '5',
+                                       '--images_dir', str(tmp_path), '--no_plot'], monkeypatch, capsys)
+    assert 'Maximum cross-correlation at: (290, 150)' in out
+    out = run_driver('test_2d_xcorr', ['--spectral', '--template', 'template.PNG', '--region', 'region.PNG',
+                                       '--images_dir', str(tmp_path), '--no_plot'], monkeypatch, capsys)
+    assert 'Maximum cross-correlation at: (288, 150)' in out
+
+
+def test_driver_signal_offset(mods, monkeypatch, capsys):
+    spatial = run_driver('signal_offset', ['--synthetic', '--no_plot'], monkeypatch, capsys)
+    spectral = run_driver('signal_offset', ['--synthetic', '--no_plot', '--spectral'], monkeypatch, capsys)
+    for out in (spatial, spectral):
+        assert 'Max at: 44136' in out
+        assert 'Number of signals shifted: 136' in out
+
+
+def test_driver_image_comparison(mods, tmp_path, monkeypatch, capsys):
+    from PIL import Image
+    im = golden('g6_cone_images')
+    g = golden('g6_cone_scan_config')
+    Image.fromarray(im['left'], 'L').save(tmp_path / 'left_cone.tiff')
+    Image.fromarray(im['right'], 'L').save(tmp_path / 'right_cone.tiff')
+    (tmp_path / 'cfg.json').write_text(str(g['config']))
+    out = run_driver('test_image_comparison',
+                     ['--images', 'cone', '--config', 'cfg.json', '--hide_depth', '--depth_output', 'depth.json',
+                      '--image_dir', str(tmp_path), '--config_dir', str(tmp_path), '--data_dir', str(tmp_path)],
+                     monkeypatch, capsys)
+    assert 'Time elapsed for sequence 1 scan' in out and 'Data saved to file depth.json' in out
+    saved = json.loads((tmp_path / 'depth.json').read_text())
+    dp_x = np.array(saved['dp_x_grid'])
+    assert dp_x.shape == im['left'].shape
+    # windows that moved in the reference's run paint their displacement into the grid
+    want = g['seq0_stage0_windows']
+    moved = want[(want[:, 5] != 0) | (want[:, 6] != 0)]
+    assert len(moved) == 38 and np.count_nonzero(dp_x) > 0
