@@ -126,6 +126,40 @@ def config3():
              pairs=int(desc.shape[0]), pairs_per_s=desc.shape[0] / ms * 1e3)
 
 
+def config4b():
+    '''Reference-faithful dense scan arithmetic: circular 31x31 surfaces (961
+    evaluations of 961 products each per pair) + maximum, device time of the
+    pair kernel on one million pairs drawn like a dense scan (same-row offsets).'''
+    rng = np.random.default_rng(4)
+    H = W = 1024
+    left = rng.random((H, W))
+    right = np.roll(left, 7, axis=1) + 0.01 * rng.random((H, W))
+    n = 1 << 20
+    ty = rng.integers(0, H - 31, size=n)
+    tx = rng.integers(128, W - 31 - 128, size=n)
+    dx = rng.integers(-128, 129, size=n)
+    desc = np.empty((n, 8), dtype=np.int64)
+    desc[:, 0] = ty * W + tx
+    desc[:, 4] = ty * W + tx + dx
+    desc[:, 1] = desc[:, 5] = W
+    desc[:, 2] = desc[:, 3] = desc[:, 6] = desc[:, 7] = 31
+    dl, dr, dd = nv.to_device(left), nv.to_device(right), nv.to_device(desc)
+    out = nv.empty(n, torch.float64)
+    for precision, tag in ((nv.ACC_F32, 'f32'), (nv.ACC_F64, 'f64')):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for it in range(3):
+            if it == 1:
+                e0.record()
+            nv.call('svamd_scan_pairs', nv.ptr(dl), nv.ptr(dr), nv.ptr(dd), n, 31, 1e-4, 1e-9, precision,
+                    nv.ptr(out), None, None, None, nv.stream_ptr())
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 2
+        emit(config='4b', what=f'svamd_scan_pairs ({tag}) device time, 2^20 pairs of 31x31 (circular surface + max)',
+             device_ms=ms, pairs_per_s=n / ms * 1e3, evals_per_s=n * 961 / ms * 1e3,
+             tflops=n * 961 * 961 * 2 / ms * 1e3 / 1e12)
+
+
 def config5():
     lib = nv.load_library()
     n = 1024
@@ -160,6 +194,6 @@ def config5():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['1', '2', '3', '5']
+    which = sys.argv[1:] or ['1', '2', '3', '4b', '5']
     for c in which:
-        {'1': config1, '2': config2, '3': config3, '5': config5}[c]()
+        {'1': config1, '2': config2, '3': config3, '4b': config4b, '5': config5}[c]()

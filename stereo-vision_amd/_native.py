@@ -126,7 +126,10 @@ def as_image(arr):
 
 def to_device(arr):
     torch = torch_cuda()
-    return torch.from_numpy(np.ascontiguousarray(arr)).cuda()
+    arr = np.ascontiguousarray(arr)
+    if not arr.flags.writeable:      # e.g. arrays backed by a PIL image buffer
+        arr = arr.copy()
+    return torch.from_numpy(arr).cuda()
 
 
 def empty(shape, dtype):

@@ -78,7 +78,7 @@ scan_pairs_kernel(const double *__restrict__ tbase, const double *__restrict__ r
     extern __shared__ __align__(16) unsigned char smem_raw[];
     __shared__ double red[17];
     __shared__ double red_d[4];
-    __shared__ int red_i[8];
+    __shared__ int red_i[8];   // up to 4 wavefronts per workgroup
     CT *Tb = reinterpret_cast<CT *>(smem_raw);
 
     for (int64_t p = blockIdx.x; p < npairs; p += gridDim.x) {
@@ -139,17 +139,24 @@ scan_pairs_kernel(const double *__restrict__ tbase, const double *__restrict__ r
             continue;
         }
 
+        // LDS images: template rows padded with zeros to a multiple of 4 columns,
+        // region rows wrapped horizontally and long enough for every 4-wide read
         const int mh = min(th, rh), mw = min(tw, rw);
-        const int rxw = rw + mw - 1;
-        CT *Rx = Tb + mh * mw;
-        for (int i = threadIdx.x; i < mh * mw; i += blockDim.x) {
-            int y = i / mw, x = i - y * mw;
-            Tb[i] = (CT)(T[y * d.t_pitch + x] - tmean);
+        const int mwp = (mw + 3) & ~3;
+        const int rxp = (rw + mwp + 4 + 3) & ~3;
+        CT *Rx = Tb + mh * mwp;
+        for (int i = threadIdx.x; i < mh * mwp; i += blockDim.x) {
+            int y = i / mwp, x = i - y * mwp;
+            Tb[i] = x < mw ? (CT)(T[y * d.t_pitch + x] - tmean) : CT(0);
         }
-        for (int i = threadIdx.x; i < rh * rxw; i += blockDim.x) {
-            int y = i / rxw, x = i - y * rxw;
-            int xs = x >= rw ? x - rw : x;
-            Rx[i] = (CT)(R[y * d.r_pitch + xs] - rmean);
+        for (int i = threadIdx.x; i < rh * rxp; i += blockDim.x) {
+            int y = i / rxp, x = i - y * rxp;
+            CT v = CT(0);
+            if (x < rw + mw - 1) {
+                int xs = x >= rw ? x - rw : x;
+                v = (CT)(R[y * d.r_pitch + xs] - rmean);
+            }
+            Rx[i] = v;
         }
         __syncthreads();
 
@@ -157,33 +164,62 @@ scan_pairs_kernel(const double *__restrict__ tbase, const double *__restrict__ r
         // wherever the normalised region is finite.
         const double scale = tn == 0 ? ((rstd > 0.0) ? 0.0 : NAN) : 1.0 / (tstd * (double)tn) / rstd;
 
+        // One task = 4 horizontally adjacent surface elements (k, l0 .. l0+3): the
+        // region row is walked with a sliding 8-value register window, so every
+        // 4-wide LDS read of template and region feeds 16 FMAs.
         BestNan mine;
         mine.best = -INFINITY;
         mine.arg = 0x7fffffff;
         mine.has_nan = 0;
-        for (int idx = threadIdx.x; idx < rn; idx += blockDim.x) {
-            const int k = idx / rw, l = idx - k * rw;
-            double acc = 0.0;
+        const int lgroups = (rw + 3) / 4;
+        for (int task = threadIdx.x; task < rh * lgroups; task += blockDim.x) {
+            const int k = task / lgroups, l0 = (task - k * lgroups) * 4;
+            double acc[4] = {0.0, 0.0, 0.0, 0.0};
             for (int m = 0; m < mh; ++m) {
                 int rr = m + k;
                 if (rr >= rh)
                     rr -= rh;
-                const CT *trow = Tb + m * mw;
-                const CT *rrow = Rx + rr * rxw + l;
-                CT part = CT(0);
-#pragma unroll 4
-                for (int n = 0; n < mw; ++n)
-                    part = fma(trow[n], rrow[n], part);
-                acc += (double)part;
+                const CT *trow = Tb + m * mwp;
+                const CT *rrow = Rx + rr * rxp + l0;
+                CT part[4] = {CT(0), CT(0), CT(0), CT(0)};
+                CT win[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    win[j] = rrow[j];
+                for (int n0 = 0; n0 < mwp; n0 += 4) {
+                    CT tv[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        tv[j] = trow[n0 + j];
+                        win[4 + j] = rrow[n0 + 4 + j];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            part[j] = fma(tv[i], win[i + j], part[j]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        win[j] = win[4 + j];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[j] += (double)part[j];
             }
-            const double v = tn == 0 ? scale : acc * scale;
-            if (surf)
-                surf[idx] = v;
-            if (isnan(v)) {
-                mine.has_nan = 1;
-            } else if (v > mine.best) {
-                mine.best = v;
-                mine.arg = idx;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (l0 + j >= rw)
+                    continue;
+                const int idx = k * rw + l0 + j;
+                const double v = tn == 0 ? scale : acc[j] * scale;
+                if (surf)
+                    surf[idx] = v;
+                if (isnan(v)) {
+                    mine.has_nan = 1;
+                } else if (v > mine.best) {      // ascending idx within a thread: first maximum kept
+                    mine.best = v;
+                    mine.arg = idx;
+                }
             }
         }
         const BestNan all = block_best(mine, red_d, red_i);
@@ -247,12 +283,16 @@ extern "C" int svamd_scan_pairs(const double *tbase, const double *rbase, const 
     SV_REQUIRE(acc_precision == SVAMD_ACC_F32 || acc_precision == SVAMD_ACC_F64, SVAMD_ERR_INVALID,
                "scan_pairs: unknown accumulation precision %d", acc_precision);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const size_t elems = (size_t)max_side * max_side + (size_t)max_side * (2 * max_side - 1);
+    const size_t side4 = ((size_t)max_side + 3) & ~(size_t)3;
+    const size_t elems = (size_t)max_side * side4 + (size_t)max_side * (((size_t)max_side + side4 + 4 + 3) & ~(size_t)3);
+    // one task per 4 surface elements of a row: small windows get small workgroups
+    const int tasks = max_side * ((max_side + 3) / 4);
+    const int threads = tasks <= 64 ? 64 : tasks <= 128 ? 128 : 256;
     const unsigned grid = (unsigned)(npairs < (1 << 20) ? npairs : (1 << 20));
     const PairDesc *pd = reinterpret_cast<const PairDesc *>(desc);
     if (acc_precision == SVAMD_ACC_F32) {
         const size_t lds = elems * sizeof(float);
-        hipLaunchKernelGGL((scan_pairs_kernel<float>), dim3(grid), dim3(256), lds, st, tbase, rbase, pd,
+        hipLaunchKernelGGL((scan_pairs_kernel<float>), dim3(grid), dim3(threads), lds, st, tbase, rbase, pd,
                            npairs, max_side, min_std, min_mean_diff, out_max, out_argmax, surfaces,
                            surf_off);
     } else {
@@ -265,7 +305,7 @@ extern "C" int svamd_scan_pairs(const double *tbase, const double *rbase, const 
                 raised = true;
             }
         }
-        hipLaunchKernelGGL((scan_pairs_kernel<double>), dim3(grid), dim3(256), lds, st, tbase, rbase, pd,
+        hipLaunchKernelGGL((scan_pairs_kernel<double>), dim3(grid), dim3(threads), lds, st, tbase, rbase, pd,
                            npairs, max_side, min_std, min_mean_diff, out_max, out_argmax, surfaces,
                            surf_off);
     }
