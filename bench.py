@@ -58,6 +58,17 @@ def synthetic_pair(height, width, seed):
     return left, right
 
 
+def measured_traffic():
+    '''HBM bytes per launch of the band kernel from the last rocprofv3 counter run
+    (collected separately: counters cannot be read from inside this process).'''
+    path = os.path.join(ROOT, 'profiles', 'band_traffic.json')
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except OSError:
+        return None
+
+
 def count_evals(height, width, win, max_disp):
     '''Number of (window, offset) pairs whose candidate box lies inside the image.'''
     nwx, nwy = width - win + 1, height - win + 1
@@ -209,6 +220,10 @@ def main():
                 'traffic': None,
             },
         }
+        traffic = measured_traffic()
+        if traffic and (H, W) == (4096, 4096):
+            line['roofline']['traffic'] = traffic['bytes_per_launch']
+            line['roofline']['traffic_source'] = traffic['source']
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(H, W, seed=1000)
         print(json.dumps(line), flush=True)
