@@ -4,6 +4,9 @@ given on the command line is loaded separately and the 4096x4096 / 31x31 / 257
 offset scan is timed with HIP events in interleaved rounds.
 
     python3 profiles/ab_band.py stereo-vision_amd/libsvamd.so /path/to/variant.so ...
+
+A path may carry extra flag bits for svamd_band_scan_u8 as path@FLAGS (e.g. @2 =
+tile-at-a-time kernel, @0x6400 = streaming kernel with 100-row segments).
 '''
 import ctypes
 import os
@@ -17,7 +20,7 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 H = W = 4096
-WIN, MD = 31, 128
+WIN, MD = 31, int(os.environ.get('AB_MAX_DISP', 128))
 
 
 def load(path):
@@ -33,7 +36,8 @@ def load(path):
 
 def main():
     paths = sys.argv[1:]
-    libs = [load(p) for p in paths]
+    extra = [int(p.split('@')[1], 0) if '@' in p else 0 for p in paths]
+    libs = [load(p.split('@')[0]) for p in paths]
     left, right = bench.synthetic_pair(H, W, 1000)
     dl, dr = torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda()
     nwy, nwx = H - WIN + 1, W - WIN + 1
@@ -49,21 +53,21 @@ def main():
         assert rc == 0, lib.svamd_last_error()
 
     ref = None
-    for lib in libs:
-        run(lib, 0)
+    for lib, fl in zip(libs, extra):
+        run(lib, fl)
         torch.cuda.synchronize()
         out = disp.clone()
         if ref is None:
             ref = out
         else:
-            assert torch.equal(ref, out), 'variants disagree'
+            assert os.environ.get('AB_NO_CHECK') or torch.equal(ref, out), 'variants disagree'
     rounds = 6
     times = [[] for _ in libs]
     for _ in range(rounds):
-        for k, lib in enumerate(libs):
+        for k, (lib, fl) in enumerate(zip(libs, extra)):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            run(lib, 1)
+            run(lib, 1 | fl)
             e1.record()
             torch.cuda.synchronize()
             times[k].append(e0.elapsed_time(e1))
