@@ -68,6 +68,31 @@ def config1():
                  gflops=2 * tmpl.size * out.size / dt / 1e9)
 
 
+def config1_device():
+    '''Device time of svamd_cross_correlate_2d alone (statistics, tables,
+    extension, sliding kernel, epilogue), buffers resident.'''
+    lib = nv.load_library()
+    rng = np.random.default_rng(2)
+    for (th, tw), (rh, rw) in (((135, 136), (433, 862)), ((31, 31), (2048, 2048)), ((64, 64), (4096, 4096)),
+                               ((200, 200), (1000, 1000))):
+        region = nv.to_device(rng.integers(0, 256, size=(rh, rw), dtype=np.uint8))
+        tmpl = nv.to_device(rng.random((th, tw)) * 255)
+        out = nv.empty((rh, rw), torch.float64)
+        ws = nv.workspace(lib.svamd_cross_correlate_2d_workspace_bytes(th, tw, rh, rw))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 3
+        for it in range(reps + 1):
+            if it == 1:
+                e0.record()
+            nv.call('svamd_cross_correlate_2d', nv.ptr(tmpl), th, tw, nv.ptr(region), nv.U8, rh, rw, 1, 1,
+                    nv.ptr(out), nv.ptr(ws), ws.numel(), nv.stream_ptr())
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        emit(config=1, what=f'svamd_cross_correlate_2d device time, {th}x{tw} template, {rh}x{rw} uint8 region, step 1',
+             device_ms=ms, evals_per_s=rh * rw / ms * 1e3, tflops=2.0 * th * tw * rh * rw / ms * 1e3 / 1e12)
+
+
 def config2():
     rng = np.random.default_rng(0)
     n = 44000
@@ -79,6 +104,22 @@ def config2():
     dt, out = timed(correlation_spectral.cross_correlate_1d_spectral, s1, s2)
     emit(config=2, what='cross_correlate_1d_spectral n=44000', seconds=dt, argmax=int(np.argmax(out)),
          lags_per_s=out.size / dt)
+    t0 = time.perf_counter()
+    lib = nv.load_library()
+    d1, d2 = nv.to_device(s1), nv.to_device(s2)
+    out = nv.empty(2 * n - 1, torch.float64)
+    ws = nv.workspace(lib.svamd_cross_correlate_1d_workspace_bytes(n))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for it in range(4):
+        if it == 1:
+            e0.record()
+        nv.call('svamd_cross_correlate_1d', nv.ptr(d1), nv.ptr(d2), n, 0, nv.ptr(out), nv.ptr(ws), ws.numel(),
+                nv.stream_ptr())
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 3
+    emit(config=2, what='svamd_cross_correlate_1d device time, n=44000', device_ms=ms,
+         tflops=2.0 * n * (2 * n - 1) / ms * 1e3 / 1e12)
     t0 = time.perf_counter()
     np.correlate(s2 - s2.mean(), s1 - s1.mean(), mode='full')
     emit(config=2, what='cpu numpy.correlate(full) of the same signals (1 thread)',
@@ -194,6 +235,6 @@ def config5():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['1', '2', '3', '4b', '5']
+    which = sys.argv[1:] or ['1', '1d', '2', '3', '4b', '5']
     for c in which:
-        {'1': config1, '2': config2, '3': config3, '4b': config4b, '5': config5}[c]()
+        {'1': config1, '1d': config1_device, '2': config2, '3': config3, '4b': config4b, '5': config5}[c]()

@@ -12,14 +12,23 @@ int sat2d_launch(const TIn *img, int h, int w, int64_t pitch, TAcc offset, TAcc 
 
 // xcorr_slide.hip
 // Two-pass mean / population std of an h x w array (NaNs optionally ignored).
+// `scratch`: stats_scratch_doubles() doubles, reusable by later calls on the stream.
+size_t stats_scratch_doubles();
 int stats_launch(const void *src, int dtype, int h, int w, int64_t pitch, bool ignore_nan, Stats *out,
-                 hipStream_t stream);
+                 double *scratch, hipStream_t stream);
 
 // Sliding dot product of a float32 template over a float32 image:
 //   out[i][j] = sum_{m<th, n<tw} t[m][n] * img[i*sy + m][j*sx + n]
-// for i < oh, j < ow; the image must cover every index touched.  Products are
-// accumulated in float32 over short runs and the runs in float64.
-int slide_launch(const float *t, int th, int tw, const float *img, int64_t img_pitch, int oh, int ow,
-                 int sx, int sy, double *out, hipStream_t stream);
+// for i < oh, j < ow.  The image has eh valid rows of ew valid columns (row pitch
+// img_pitch, a multiple of 4 unless eh == 1); with sx == 1 anything beyond them
+// reads as 0, with sx > 1 the image must cover every index touched.  Products are
+// accumulated in float32 over short runs and the runs in float64.  `pack` and
+// `partial` are scratch of slide_pack_floats() floats / slide_partial_doubles()
+// doubles.
+size_t slide_pack_floats(int th, int tw);
+size_t slide_partial_doubles(int tw, int64_t oh, int64_t ow);
+int slide_launch(const float *t, int th, int tw, const float *img, int64_t img_pitch, int eh, int ew,
+                 int oh, int ow, int sx, int sy, double *out, float *pack, double *partial,
+                 hipStream_t stream);
 
 }  // namespace svamd

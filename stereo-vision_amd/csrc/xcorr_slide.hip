@@ -13,6 +13,12 @@
 
 namespace svamd {
 
+inline int grid_for(int64_t total, int block = 256, int cap = 65536)
+{
+    int64_t g = (total + block - 1) / block;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
 // ---- statistics ---------------------------------------------------------------
 // One block; two passes (mean, then squared deviations), all in float64, the
 // same two-pass definition numpy's mean/std and nanmean/nanstd use.
@@ -52,12 +58,82 @@ stats_kernel(const void *__restrict__ src, int dtype, int h, int w, int64_t pitc
     }
 }
 
-int stats_launch(const void *src, int dtype, int h, int w, int64_t pitch, bool ignore_nan, Stats *out,
-                 hipStream_t stream)
+// Large arrays: the same two passes spread over many blocks.  Pass 0 leaves
+// per-block (sum, count) in `partial`, pass 1 per-block sums of squared deviations
+// from the mean already in `out`; stats_final_kernel folds the partials.
+constexpr int STATS_BLOCKS = 512;
+constexpr int64_t STATS_SINGLE_BLOCK_MAX = 1 << 16;
+
+__global__ void __launch_bounds__(256)
+stats_partial_kernel(const void *__restrict__ src, int dtype, int h, int w, int64_t pitch, int ignore_nan,
+                     int pass, const Stats *__restrict__ st, double *__restrict__ partial)
 {
-    hipLaunchKernelGGL(stats_kernel, dim3(1), dim3(1024), 0, stream, src, dtype, h, w, pitch,
-                       ignore_nan ? 1 : 0, out);
-    SV_LAUNCH_CHECK();
+    __shared__ double red[17];
+    const int64_t total = (int64_t)h * w;
+    const double mean = pass ? st->mean : 0.0;
+    double s = 0.0, c = 0.0;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t y = i / w, x = i - y * w;
+        double v = load_as_double(src, dtype, y * pitch + x);
+        if (!ignore_nan || !isnan(v)) {
+            const double d = v - mean;
+            s += pass ? d * d : v;
+            c += 1.0;
+        }
+    }
+    s = block_sum(s, red);
+    c = block_sum(c, red);
+    if (threadIdx.x == 0) {
+        partial[2 * blockIdx.x] = s;
+        partial[2 * blockIdx.x + 1] = c;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+stats_final_kernel(const double *__restrict__ partial, int nblocks, int pass, Stats *__restrict__ out)
+{
+    __shared__ double red[17];
+    double s = 0.0, c = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += blockDim.x) {
+        s += partial[2 * i];
+        c += partial[2 * i + 1];
+    }
+    s = block_sum(s, red);
+    c = block_sum(c, red);
+    if (threadIdx.x == 0) {
+        if (pass == 0) {
+            out->mean = s / c;
+            out->count = c;
+            out->pad = 0.0;
+        } else {
+            out->std = sqrt(s / c);
+        }
+    }
+}
+
+size_t stats_scratch_doubles() { return 2 * STATS_BLOCKS; }
+
+int stats_launch(const void *src, int dtype, int h, int w, int64_t pitch, bool ignore_nan, Stats *out,
+                 double *scratch, hipStream_t stream)
+{
+    const int64_t total = (int64_t)h * w;
+    if (total <= STATS_SINGLE_BLOCK_MAX) {
+        hipLaunchKernelGGL(stats_kernel, dim3(1), dim3(1024), 0, stream, src, dtype, h, w, pitch,
+                           ignore_nan ? 1 : 0, out);
+        SV_LAUNCH_CHECK();
+        return SVAMD_OK;
+    }
+    int64_t nb = (total + 256 * 16 - 1) / (256 * 16);
+    if (nb > STATS_BLOCKS)
+        nb = STATS_BLOCKS;
+    for (int pass = 0; pass < 2; ++pass) {
+        hipLaunchKernelGGL(stats_partial_kernel, dim3((unsigned)nb), dim3(256), 0, stream, src, dtype, h, w,
+                           pitch, ignore_nan ? 1 : 0, pass, out, scratch);
+        SV_LAUNCH_CHECK();
+        hipLaunchKernelGGL(stats_final_kernel, dim3(1), dim3(256), 0, stream, scratch, (int)nb, pass, out);
+        SV_LAUNCH_CHECK();
+    }
     return SVAMD_OK;
 }
 
@@ -164,10 +240,9 @@ extend_1d_circular_kernel(const double *__restrict__ sig, int64_t nt, int64_t ns
 }
 
 // ---- the sliding dot product --------------------------------------------------------
-// One thread per output; a block covers 64 x 4 outputs so that the lanes of a
-// wavefront read consecutive image columns (coalesced when sx == 1).  Template
-// values are wave-uniform and come in through the scalar data path.  Each run of
-// up to RUN products is accumulated in float32 and the runs are added in
+// Strided columns (sx > 1): one thread per output; a block covers 64 x 4 outputs.
+// Template values are wave-uniform and come in through the scalar data path.  Each
+// run of up to RUN products is accumulated in float32 and the runs are added in
 // float64, which keeps the rounding error of long sums near 1e-7 relative.
 constexpr int SLIDE_BX = 64, SLIDE_BY = 4, SLIDE_RUN = 128;
 
@@ -195,13 +270,265 @@ slide_kernel(const float *__restrict__ t, int th, int tw, const float *__restric
     out[(int64_t)i * ow + j] = acc;
 }
 
-int slide_launch(const float *t, int th, int tw, const float *img, int64_t img_pitch, int oh, int ow,
-                 int sx, int sy, double *out, hipStream_t stream)
+// Unit column stride (sx == 1): register-tiled, LDS-staged kernel.
+//
+// A wavefront owns one output row and 512 output columns, 8 consecutive columns
+// per lane.  The products of one template row are issued as packed FMAs over
+// PAIRS of template columns: for an even output column j
+//     out[j] += (T0[2k], T0[2k+1]) . (img[j+2k], img[j+2k+1]),        T0 = t
+// and for the odd column j+1, with the template shifted right by one,
+//     out[j+1] += (T1[2k], T1[2k+1]) . (img[j+2k], img[j+2k+1]),      T1 = (0, t)
+// so both use the same aligned image pairs: a lane keeps a sliding window of 7
+// pairs in registers and adds 4 new pairs (two 16-byte LDS reads) per 32 packed
+// FMAs.  The template pairs are wave-uniform and arrive through the scalar data
+// path.  The two halves of each accumulator pair are added at the end.
+//
+// A workgroup is up to 8 wavefronts = 8 consecutive output rows of the same
+// column tile and template-column chunk (at most 512 template columns; the
+// partial sums of several chunks are added by slide_reduce_kernel).  It walks down
+// the image rows its outputs touch, staging up to 4 rows at a time in LDS
+// (double-buffered: the next rows are fetched into registers while the current
+// ones are used); image row r serves output row i as template row r - i * sy.
+// LDS rows are stored with 16-byte slots swapped inside every other 256-byte line
+// so that the 32-byte lane stride of the window reads is free of bank conflicts.
+constexpr int ST_TILE = 512;     // output columns per wavefront
+constexpr int ST_CHUNK = 512;    // template columns per workgroup
+constexpr int ST_WAVES = 8;      // output rows per workgroup
+constexpr int ST_ROWS = 4;       // image rows staged per step
+constexpr int ST_STAGE_Q = 6;    // 16-byte pieces a thread stages per step
+constexpr int ST_FLUSH = 1024;   // products accumulated in float32 before they are folded into float64
+
+struct SlideGeom {
+    int th, tw, lp;        // template shape; lp = packed template row length (multiple of 8, > tw)
+    int oh, ow, sy;
+    int eh, ew;            // valid image rows / columns (anything beyond reads as 0)
+    int64_t pitch;
+    int waves, grows, rowlen;
+};
+
+typedef float f2v __attribute__((ext_vector_type(2)));
+typedef float f4v __attribute__((ext_vector_type(4)));
+
+// Packed template: for every row m, T0 = (t[m][0..tw-1], 0...) and T1 = (0, t[m][0..tw-1], 0...),
+// lp floats each.
+__global__ void __launch_bounds__(256)
+pack_template_kernel(const float *__restrict__ tp, int th, int tw, int lp, float *__restrict__ tpk)
 {
-    dim3 grid((ow + SLIDE_BX - 1) / SLIDE_BX, (oh + SLIDE_BY - 1) / SLIDE_BY);
-    hipLaunchKernelGGL(slide_kernel, grid, dim3(SLIDE_BX, SLIDE_BY), 0, stream, t, th, tw, img, img_pitch,
-                       oh, ow, sx, sy, out);
+    const int64_t total = (int64_t)th * 2 * lp;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int n = (int)(i % lp);
+        const int which = (int)((i / lp) & 1);
+        const int64_t m = i / (2 * (int64_t)lp);
+        const int src = n - which;
+        tpk[i] = (src >= 0 && src < tw) ? tp[m * tw + src] : 0.0f;
+    }
+}
+
+// The 8 floats at logical columns 8b .. 8b+7 of a staged row, as 4 pairs.
+__device__ __forceinline__ void slide_load_block(const float *row, int b, f2v (&w)[4])
+{
+    const int c = 8 * b, sw = ((b >> 3) & 1) << 2;
+    const f4v lo = *reinterpret_cast<const f4v *>(row + c + sw);
+    const f4v hi = *reinterpret_cast<const f4v *>(row + c + (4 ^ sw));
+    w[0] = lo.xy;
+    w[1] = lo.zw;
+    w[2] = hi.xy;
+    w[3] = hi.zw;
+}
+
+__device__ __forceinline__ void slide_group(f2v (&ae)[4], f2v (&ao)[4], const f2v (&cur)[4],
+                                            const f2v (&nxt)[4], const float *__restrict__ t0,
+                                            const float *__restrict__ t1)
+{
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const f2v a = f2v{t0[2 * s], t0[2 * s + 1]};
+        const f2v b = f2v{t1[2 * s], t1[2 * s + 1]};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const f2v w = e + s < 4 ? cur[e + s] : nxt[e + s - 4];
+            ae[e] = __builtin_elementwise_fma(a, w, ae[e]);
+            ao[e] = __builtin_elementwise_fma(b, w, ao[e]);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(ST_WAVES *WAVE)
+slide_tiled_kernel(SlideGeom g, const float *__restrict__ tpk, const float *__restrict__ img,
+                   double *__restrict__ out)
+{
+    extern __shared__ __align__(16) float st_lds[];
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
+    const int nthreads = g.waves * WAVE;
+    const int c0 = blockIdx.x * ST_TILE;
+    const int i0 = blockIdx.y * g.waves;
+    const int n0 = blockIdx.z * ST_CHUNK;
+    const int chunk = min(ST_CHUNK, g.lp - n0);
+    const int groups = chunk / 8;
+    const int i = i0 + wave;
+    const bool has_row = i < g.oh;
+    const int r_first = i0 * g.sy;
+    const int r_end = (min(i0 + g.waves, g.oh) - 1) * g.sy + g.th;   // exclusive
+    const int nsteps = (r_end - r_first + g.grows - 1) / g.grows;
+    const int qpr = g.rowlen / 4, total_q = g.grows * qpr;
+
+    f4v stage[ST_STAGE_Q];
+    auto fetch = [&](int step) {
+#pragma unroll
+        for (int u = 0; u < ST_STAGE_Q; ++u) {
+            const int q = threadIdx.x + u * nthreads;
+            f4v v = {0.f, 0.f, 0.f, 0.f};
+            if (q < total_q) {
+                const int rr = q / qpr, cq = q - rr * qpr;
+                const int r = r_first + step * g.grows + rr;
+                const int col = c0 + n0 + 4 * cq;
+                if (r < r_end && r < g.eh && col < g.ew) {
+                    v = *reinterpret_cast<const f4v *>(img + (int64_t)r * g.pitch + col);
+                    if (col + 1 >= g.ew) v.y = 0.f;
+                    if (col + 2 >= g.ew) v.z = 0.f;
+                    if (col + 3 >= g.ew) v.w = 0.f;
+                }
+            }
+            stage[u] = v;
+        }
+    };
+    auto store = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < ST_STAGE_Q; ++u) {
+            const int q = threadIdx.x + u * nthreads;
+            if (q < total_q) {
+                const int rr = q / qpr, cq = q - rr * qpr;
+                const int phys = (4 * cq) ^ ((((4 * cq) >> 6) & 1) << 2);
+                *reinterpret_cast<f4v *>(st_lds + (buf * g.grows + rr) * g.rowlen + phys) = stage[u];
+            }
+        }
+    };
+
+    f2v ae[4] = {}, ao[4] = {};
+    double de[4] = {}, dodd[4] = {};
+    int pending = 0;
+
+    fetch(0);
+    store(0);
+    __syncthreads();
+    for (int step = 0; step < nsteps; ++step) {
+        if (step + 1 < nsteps)
+            fetch(step + 1);
+        const float *buf = st_lds + (step & 1) * g.grows * g.rowlen;
+        for (int rr = 0; rr < g.grows; ++rr) {
+            const int r = r_first + step * g.grows + rr;
+            const int m = r - i * g.sy;
+            if (!has_row || r >= r_end || m < 0 || m >= g.th)
+                continue;                                     // wave-uniform
+            const float *row = buf + rr * g.rowlen;
+            const float *t0 = tpk + ((int64_t)m * 2) * g.lp + n0;
+            const float *t1 = t0 + g.lp;
+            f2v cur[4], nxt[4];
+            slide_load_block(row, lane, cur);
+            int gi = 0;
+            for (; gi + 2 <= groups; gi += 2) {
+                slide_load_block(row, lane + gi + 1, nxt);
+                slide_group(ae, ao, cur, nxt, t0 + 8 * gi, t1 + 8 * gi);
+                slide_load_block(row, lane + gi + 2, cur);
+                slide_group(ae, ao, nxt, cur, t0 + 8 * gi + 8, t1 + 8 * gi + 8);
+            }
+            if (gi < groups) {
+                slide_load_block(row, lane + gi + 1, nxt);
+                slide_group(ae, ao, cur, nxt, t0 + 8 * gi, t1 + 8 * gi);
+            }
+            pending += chunk;
+            if (pending >= ST_FLUSH) {
+                pending = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    de[e] += (double)(ae[e].x + ae[e].y);
+                    dodd[e] += (double)(ao[e].x + ao[e].y);
+                    ae[e] = f2v{0.f, 0.f};
+                    ao[e] = f2v{0.f, 0.f};
+                }
+            }
+        }
+        if (step + 1 < nsteps)
+            store((step + 1) & 1);
+        __syncthreads();
+    }
+    if (!has_row)
+        return;
+    double *dst = out + ((int64_t)blockIdx.z * g.oh + i) * g.ow;
+    const int j0 = c0 + 8 * lane;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (j0 + 2 * e < g.ow)
+            dst[j0 + 2 * e] = de[e] + (double)(ae[e].x + ae[e].y);
+        if (j0 + 2 * e + 1 < g.ow)
+            dst[j0 + 2 * e + 1] = dodd[e] + (double)(ao[e].x + ao[e].y);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+slide_reduce_kernel(const double *__restrict__ partial, int nz, int64_t total, double *__restrict__ out)
+{
+    const int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (idx >= total)
+        return;
+    double s = 0.0;
+    for (int z = 0; z < nz; ++z)
+        s += partial[(int64_t)z * total + idx];
+    out[idx] = s;
+}
+
+static int slide_lp(int tw) { return (int)align_up((size_t)tw + 1, 8); }
+static int slide_nz(int tw) { return (slide_lp(tw) + ST_CHUNK - 1) / ST_CHUNK; }
+
+size_t slide_pack_floats(int th, int tw) { return (size_t)th * 2 * slide_lp(tw); }
+
+size_t slide_partial_doubles(int tw, int64_t oh, int64_t ow)
+{
+    const int nz = slide_nz(tw);
+    return nz > 1 ? (size_t)nz * (size_t)oh * (size_t)ow : 0;
+}
+
+int slide_launch(const float *t, int th, int tw, const float *img, int64_t img_pitch, int eh, int ew,
+                 int oh, int ow, int sx, int sy, double *out, float *pack, double *partial,
+                 hipStream_t stream)
+{
+    if (sx != 1) {
+        dim3 grid((ow + SLIDE_BX - 1) / SLIDE_BX, (oh + SLIDE_BY - 1) / SLIDE_BY);
+        hipLaunchKernelGGL(slide_kernel, grid, dim3(SLIDE_BX, SLIDE_BY), 0, stream, t, th, tw, img,
+                           img_pitch, oh, ow, sx, sy, out);
+        SV_LAUNCH_CHECK();
+        return SVAMD_OK;
+    }
+    SlideGeom g;
+    g.th = th; g.tw = tw; g.lp = slide_lp(tw);
+    g.oh = oh; g.ow = ow; g.sy = sy; g.eh = eh; g.ew = ew; g.pitch = img_pitch;
+    const int nz = slide_nz(tw);
+    g.waves = oh < ST_WAVES ? oh : ST_WAVES;
+    g.rowlen = ST_TILE + (g.lp < ST_CHUNK ? g.lp : ST_CHUNK) + 8;
+    const int qpr = g.rowlen / 4;
+    g.grows = ST_STAGE_Q * g.waves * WAVE / qpr;
+    if (g.grows > ST_ROWS) g.grows = ST_ROWS;
+    const int64_t rows_touched = (int64_t)(g.waves - 1) * sy + th;
+    if (g.grows > rows_touched) g.grows = (int)rows_touched;
+    SV_REQUIRE(g.grows >= 1, SVAMD_ERR_LIMIT, "slide: staging does not fit");
+    const int64_t gy = ((int64_t)oh + g.waves - 1) / g.waves;
+    SV_REQUIRE(gy <= 65535, SVAMD_ERR_LIMIT, "slide: too many output rows (%d)", oh);
+    hipLaunchKernelGGL(pack_template_kernel, dim3(grid_for((int64_t)th * 2 * g.lp)), dim3(256), 0, stream, t,
+                       th, tw, g.lp, pack);
     SV_LAUNCH_CHECK();
+    dim3 grid((ow + ST_TILE - 1) / ST_TILE, (unsigned)gy, nz);
+    const size_t lds = (size_t)2 * g.grows * g.rowlen * sizeof(float);
+    hipLaunchKernelGGL(slide_tiled_kernel, grid, dim3(g.waves * WAVE), lds, stream, g, pack, img,
+                       nz > 1 ? partial : out);
+    SV_LAUNCH_CHECK();
+    if (nz > 1) {
+        const int64_t total = (int64_t)oh * ow;
+        hipLaunchKernelGGL(slide_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+                           partial, nz, total, out);
+        SV_LAUNCH_CHECK();
+    }
     return SVAMD_OK;
 }
 
@@ -292,12 +619,6 @@ scale_1d_kernel(double *__restrict__ out, int64_t total, double divisor, int use
     out[idx] = v;
 }
 
-inline int grid_for(int64_t total, int block = 256, int cap = 65536)
-{
-    int64_t g = (total + block - 1) / block;
-    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
-}
-
 }  // namespace svamd
 
 using namespace svamd;
@@ -330,8 +651,9 @@ extern "C" size_t svamd_cross_correlate_2d_workspace_bytes(int th, int tw, int r
     if (th <= 0 || tw <= 0 || rh <= 0 || rw <= 0)
         return 0;
     A1Layout L = a1_layout(th, tw, rh, rw);
-    return 2 * 256 + align_up(L.n_tp * 4, 256) + align_up(L.n_tsat * 8, 256) +
-           2 * align_up(L.n_sat * 8, 256) + align_up(L.n_ext * 4, 256);
+    return 2 * 256 + align_up(stats_scratch_doubles() * 8, 256) + align_up(L.n_tp * 4, 256) + align_up(L.n_tsat * 8, 256) +
+           2 * align_up(L.n_sat * 8, 256) + align_up(L.n_ext * 4, 256) +
+           align_up(slide_pack_floats(th, tw) * 4, 256) + align_up(slide_partial_doubles(tw, rh, rw) * 8, 256);
 }
 
 extern "C" int svamd_cross_correlate_2d(const double *tmpl, int th, int tw, const void *region,
@@ -355,15 +677,18 @@ extern "C" int svamd_cross_correlate_2d(const double *tmpl, int th, int tw, cons
     Carver ws(workspace);
     Stats *tst = ws.take<Stats>(1);
     Stats *rst = ws.take<Stats>(1);
+    double *sscr = ws.take<double>(stats_scratch_doubles());
     float *tp = ws.take<float>(L.n_tp);
     double *tsat = ws.take<double>(L.n_tsat);
     void *s1 = ws.take<double>(L.n_sat);  // int64 or double: both 8 bytes
     void *s2 = ws.take<double>(L.n_sat);
     float *ext = ws.take<float>(L.n_ext);
+    float *pack = ws.take<float>(slide_pack_floats(th, tw));
+    double *partial = ws.take<double>(slide_partial_doubles(tw, rh, rw));
 
     int rc;
-    if ((rc = stats_launch(tmpl, SVAMD_F64, th, tw, tw, true, tst, st)) != SVAMD_OK) return rc;
-    if ((rc = stats_launch(region, region_dtype, rh, rw, rw, false, rst, st)) != SVAMD_OK) return rc;
+    if ((rc = stats_launch(tmpl, SVAMD_F64, th, tw, tw, true, tst, sscr, st)) != SVAMD_OK) return rc;
+    if ((rc = stats_launch(region, region_dtype, rh, rw, rw, false, rst, sscr, st)) != SVAMD_OK) return rc;
     hipLaunchKernelGGL(prep_template_kernel, dim3(grid_for((int64_t)L.n_tp)), dim3(256), 0, st, tmpl,
                        SVAMD_F64, th, tw, (int64_t)tw, th, tw, tst, tp);
     SV_LAUNCH_CHECK();
@@ -374,7 +699,8 @@ extern "C" int svamd_cross_correlate_2d(const double *tmpl, int th, int tw, cons
     hipLaunchKernelGGL(extend_kernel, dim3(grid_for((int64_t)L.n_ext)), dim3(256), 0, st, region,
                        region_dtype, rh, rw, (int64_t)rw, 0, 0, rst, L.eh, L.ew, L.epitch, ext);
     SV_LAUNCH_CHECK();
-    if ((rc = slide_launch(tp, th, tw, ext, L.epitch, orows, ocols, step_x, step_y, out, st)) != SVAMD_OK)
+    if ((rc = slide_launch(tp, th, tw, ext, L.epitch, L.eh, L.ew, orows, ocols, step_x, step_y, out, pack,
+                           partial, st)) != SVAMD_OK)
         return rc;
     const int64_t total = (int64_t)orows * ocols;
     dim3 eg((unsigned)((total + 255) / 256));
@@ -397,7 +723,8 @@ extern "C" size_t svamd_cross_correlate_2d_spectral_workspace_bytes(int th, int 
         return 0;
     const int mh = th < rh ? th : rh, mw = tw < rw ? tw : rw;
     const size_t epitch = align_up((size_t)(rw + mw - 1), 4);
-    return 2 * 256 + align_up((size_t)mh * mw * 4, 256) + align_up((size_t)(rh + mh - 1) * epitch * 4, 256);
+    return 2 * 256 + align_up(stats_scratch_doubles() * 8, 256) + align_up((size_t)mh * mw * 4, 256) + align_up((size_t)(rh + mh - 1) * epitch * 4, 256) +
+           align_up(slide_pack_floats(mh, mw) * 4, 256) + align_up(slide_partial_doubles(mw, rh, rw) * 8, 256);
 }
 
 extern "C" int svamd_cross_correlate_2d_spectral(const void *tmpl, int tmpl_dtype, int th, int tw,
@@ -423,12 +750,15 @@ extern "C" int svamd_cross_correlate_2d_spectral(const void *tmpl, int tmpl_dtyp
     Carver ws(workspace);
     Stats *tst = ws.take<Stats>(1);
     Stats *rst = ws.take<Stats>(1);
+    double *sscr = ws.take<double>(stats_scratch_doubles());
     float *tp = ws.take<float>((size_t)mh * mw);
     float *ext = ws.take<float>((size_t)eh * epitch);
+    float *pack = ws.take<float>(slide_pack_floats(mh, mw));
+    double *partial = ws.take<double>(slide_partial_doubles(mw, rh, rw));
 
     int rc;
-    if ((rc = stats_launch(tmpl, tmpl_dtype, th, tw, tw, false, tst, st)) != SVAMD_OK) return rc;
-    if ((rc = stats_launch(region, region_dtype, rh, rw, rw, false, rst, st)) != SVAMD_OK) return rc;
+    if ((rc = stats_launch(tmpl, tmpl_dtype, th, tw, tw, false, tst, sscr, st)) != SVAMD_OK) return rc;
+    if ((rc = stats_launch(region, region_dtype, rh, rw, rw, false, rst, sscr, st)) != SVAMD_OK) return rc;
     // template minus its mean, cropped top-left to the region's shape
     hipLaunchKernelGGL(prep_template_kernel, dim3(grid_for((int64_t)mh * mw)), dim3(256), 0, st, tmpl,
                        tmpl_dtype, th, tw, (int64_t)tw, mh, mw, tst, tp);
@@ -437,7 +767,8 @@ extern "C" int svamd_cross_correlate_2d_spectral(const void *tmpl, int tmpl_dtyp
     hipLaunchKernelGGL(extend_kernel, dim3(grid_for((int64_t)eh * epitch)), dim3(256), 0, st, region,
                        region_dtype, rh, rw, (int64_t)rw, 1, 1, rst, eh, ew, epitch, ext);
     SV_LAUNCH_CHECK();
-    if ((rc = slide_launch(tp, mh, mw, ext, epitch, rh, rw, 1, 1, out, st)) != SVAMD_OK) return rc;
+    if ((rc = slide_launch(tp, mh, mw, ext, epitch, eh, ew, rh, rw, 1, 1, out, pack, partial, st)) != SVAMD_OK)
+        return rc;
     const int64_t total = (int64_t)rh * rw;
     hipLaunchKernelGGL(circular_epilogue_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
                        out, total, (double)th * (double)tw, min_std, min_mean_diff, tst, rst);
@@ -450,7 +781,9 @@ extern "C" size_t svamd_cross_correlate_1d_workspace_bytes(int64_t n)
 {
     if (n <= 0)
         return 0;
-    return 2 * 256 + align_up((size_t)n * 4, 256) + align_up((size_t)(3 * n - 2) * 4, 256);
+    return 2 * 256 + align_up(stats_scratch_doubles() * 8, 256) + align_up((size_t)n * 4, 256) + align_up((size_t)(3 * n - 2) * 4, 256) +
+           align_up(slide_pack_floats(1, (int)n) * 4, 256) +
+           align_up(slide_partial_doubles((int)n, 1, 2 * n - 1) * 8, 256);
 }
 
 extern "C" int svamd_cross_correlate_1d(const double *v1, const double *v2, int64_t n, int normalised,
@@ -466,18 +799,22 @@ extern "C" int svamd_cross_correlate_1d(const double *v1, const double *v2, int6
     Carver ws(workspace);
     Stats *s1 = ws.take<Stats>(1);
     Stats *s2 = ws.take<Stats>(1);
+    double *sscr = ws.take<double>(stats_scratch_doubles());
     float *tp = ws.take<float>((size_t)n);
     float *ext = ws.take<float>((size_t)(3 * n - 2));
+    float *pack = ws.take<float>(slide_pack_floats(1, (int)n));
+    double *partial = ws.take<double>(slide_partial_doubles((int)n, 1, 2 * n - 1));
     int rc;
-    if ((rc = stats_launch(v1, SVAMD_F64, 1, (int)n, n, false, s1, st)) != SVAMD_OK) return rc;
-    if ((rc = stats_launch(v2, SVAMD_F64, 1, (int)n, n, false, s2, st)) != SVAMD_OK) return rc;
+    if ((rc = stats_launch(v1, SVAMD_F64, 1, (int)n, n, false, s1, sscr, st)) != SVAMD_OK) return rc;
+    if ((rc = stats_launch(v2, SVAMD_F64, 1, (int)n, n, false, s2, sscr, st)) != SVAMD_OK) return rc;
     hipLaunchKernelGGL(prep_template_kernel, dim3(grid_for(n)), dim3(256), 0, st, v1, SVAMD_F64, 1, (int)n,
                        n, 1, (int)n, s1, tp);
     SV_LAUNCH_CHECK();
     hipLaunchKernelGGL(extend_1d_full_kernel, dim3(grid_for(3 * n - 2)), dim3(256), 0, st, v2, n, s2, ext);
     SV_LAUNCH_CHECK();
     const int64_t total = 2 * n - 1;
-    if ((rc = slide_launch(tp, 1, (int)n, ext, 3 * n - 2, 1, (int)total, 1, 1, out, st)) != SVAMD_OK)
+    if ((rc = slide_launch(tp, 1, (int)n, ext, 3 * n - 2, 1, (int)(3 * n - 2), 1, (int)total, 1, 1, out, pack,
+                           partial, st)) != SVAMD_OK)
         return rc;
     hipLaunchKernelGGL(scale_1d_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, out, total,
                        (double)n, normalised ? 1 : 0, normalised ? 1 : 0, s1, s2);
@@ -490,7 +827,9 @@ extern "C" size_t svamd_cross_correlate_1d_spectral_workspace_bytes(int64_t nt, 
 {
     if (nt <= 0 || ns <= 0)
         return 0;
-    return 256 + align_up((size_t)nt * 4, 256) + align_up((size_t)(ns + 2 * nt - 2) * 4, 256);
+    return 256 + align_up(stats_scratch_doubles() * 8, 256) + align_up((size_t)nt * 4, 256) + align_up((size_t)(ns + 2 * nt - 2) * 4, 256) +
+           align_up(slide_pack_floats(1, (int)nt) * 4, 256) +
+           align_up(slide_partial_doubles((int)nt, 1, ns + nt - 1) * 8, 256);
 }
 
 extern "C" int svamd_cross_correlate_1d_spectral(const double *tmpl, int64_t nt, const double *signal,
@@ -507,18 +846,22 @@ extern "C" int svamd_cross_correlate_1d_spectral(const double *tmpl, int64_t nt,
     hipStream_t st = static_cast<hipStream_t>(stream);
     Carver ws(workspace);
     Stats *s1 = ws.take<Stats>(1);
+    double *sscr = ws.take<double>(stats_scratch_doubles());
     float *tp = ws.take<float>((size_t)nt);
     float *ext = ws.take<float>((size_t)(ns + 2 * nt - 2));
+    float *pack = ws.take<float>(slide_pack_floats(1, (int)nt));
+    double *partial = ws.take<double>(slide_partial_doubles((int)nt, 1, ns + nt - 1));
     const int64_t N = ns + nt - 1;
     int rc;
-    if ((rc = stats_launch(tmpl, SVAMD_F64, 1, (int)nt, nt, false, s1, st)) != SVAMD_OK) return rc;
+    if ((rc = stats_launch(tmpl, SVAMD_F64, 1, (int)nt, nt, false, s1, sscr, st)) != SVAMD_OK) return rc;
     hipLaunchKernelGGL(prep_template_kernel, dim3(grid_for(nt)), dim3(256), 0, st, tmpl, SVAMD_F64, 1,
                        (int)nt, nt, 1, (int)nt, s1, tp);
     SV_LAUNCH_CHECK();
     hipLaunchKernelGGL(extend_1d_circular_kernel, dim3(grid_for(N + nt - 1)), dim3(256), 0, st, signal, nt,
                        ns, ext);
     SV_LAUNCH_CHECK();
-    if ((rc = slide_launch(tp, 1, (int)nt, ext, N + nt - 1, 1, (int)N, 1, 1, out, st)) != SVAMD_OK)
+    if ((rc = slide_launch(tp, 1, (int)nt, ext, N + nt - 1, 1, (int)(N + nt - 1), 1, (int)N, 1, 1, out, pack,
+                           partial, st)) != SVAMD_OK)
         return rc;
     hipLaunchKernelGGL(scale_1d_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, out, N,
                        (double)nt, 1, 0, s1, s1);

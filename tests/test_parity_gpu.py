@@ -80,6 +80,23 @@ def test_spatial_float_region_and_constant_patches(mods, oracle):
     assert np.isnan(out).all()
 
 
+@pytest.mark.parametrize('tshape,rshape,sx,sy', [((9, 13), (40, 56), 1, 1), ((17, 31), (70, 1100), 1, 2),
+                                                 ((5, 600), (23, 1300), 1, 1), ((33, 8), (90, 530), 1, 5),
+                                                 ((3, 1025), (9, 1030), 1, 3), ((12, 7), (30, 64), 3, 1)])
+def test_spatial_unit_column_stride_shapes(mods, oracle, tshape, rshape, sx, sy):
+    '''Shapes that walk the tiled kernel through several column tiles, template
+    chunks, row strides and ragged edges (uint8 and float regions).'''
+    rng = np.random.default_rng(tshape[1] * 7 + rshape[1])
+    region = rng.integers(0, 256, size=rshape, dtype=np.uint8)
+    template = rng.random(tshape) * 255
+    template[rng.random(tshape) < 0.1] = np.nan
+    out = quiet(mods['c'].cross_correlate_2d, template, region, sx, sy)
+    assert_surface_close(out, oracle.cross_correlate_2d(template, region, sx, sy), SURFACE_TOL, 'u8 region')
+    fregion = rng.random(rshape)
+    out = quiet(mods['c'].cross_correlate_2d, template, fregion, sx, sy)
+    assert_surface_close(out, oracle.cross_correlate_2d(template, fregion, sx, sy), SURFACE_TOL, 'float region')
+
+
 def test_spatial_template_exceeds_region(mods):
     with pytest.raises(Exception, match='Dimensions of template must not exceed those of region.'):
         mods['c'].cross_correlate_2d(np.zeros((5, 5)), np.zeros((4, 9), np.uint8))
@@ -110,6 +127,17 @@ def test_g4_spectral_rand256(mods):
     out = mods['s'].cross_correlate_2d_spectral(t, r)
     assert_surface_close(out.ravel()[idx], g['sample_val'], SURFACE_TOL, 'rand256')
     assert int(np.argmax(out)) == int(g['argmax'])
+
+
+@pytest.mark.parametrize('tshape,rshape', [((70, 70), (80, 90)), ((100, 700), (100, 700)), ((90, 40), (65, 600)),
+                                           ((3, 1100), (66, 1200))])
+def test_spectral_large_shapes_vs_oracle(mods, oracle, tshape, rshape):
+    '''Non-power-of-two shapes beyond the pair kernel: padded, cropped and wide
+    templates through the sliding kernel.'''
+    rng = np.random.default_rng(tshape[0] + rshape[1])
+    t, r = rng.random(tshape), rng.random(rshape)
+    out = mods['s'].cross_correlate_2d_spectral(t, r)
+    assert_surface_close(out, oracle.cross_correlate_2d_spectral(t, r), SURFACE_TOL, 'large circular')
 
 
 def test_spectral_large_low_std_branches(mods):
@@ -144,6 +172,18 @@ def test_g5_1d(mods):
     assert abs(int(np.argmax(full)) - int(g['cs_xc_norm_argmax'])) <= 1
     fs = s.cross_correlate_1d_spectral(np.cos(x), -np.sin(x))
     close_1d(fs[::16], g['cs_spec_dec'], 'cos/sin spectral')
+
+
+@pytest.mark.parametrize('n', [1, 2, 7, 511, 512, 513, 1500])
+def test_1d_lengths_vs_oracle(mods, oracle, n):
+    rng = np.random.default_rng(n)
+    v1, v2 = rng.standard_normal(n) + 3, rng.standard_normal(n) - 1
+    close_1d(quiet(mods['c'].cross_correlate_1d, v1, v2), oracle.cross_correlate_1d(v1, v2), f'xc n={n}')
+    if n > 1:
+        close_1d(mods['s'].cross_correlate_1d_spectral(v1, v2), oracle.cross_correlate_1d_spectral(v1, v2),
+                 f'spectral n={n}')
+        close_1d(mods['s'].cross_correlate_1d_spectral(v1[:n // 2 + 1], v2),
+                 oracle.cross_correlate_1d_spectral(v1[:n // 2 + 1], v2), f'spectral uneven n={n}')
 
 
 def test_1d_unequal_raises(mods):
