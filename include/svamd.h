@@ -182,6 +182,36 @@ int svamd_band_scan_u8(const uint8_t *left, const uint8_t *right, int H, int W,
                        int32_t *out_disp, double *out_val, double *scores,
                        void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- displacement grids: the accumulation after a scan ---------------------------
+ * test_image_comparison.py:61-92.  Every window of a sequence paints dp_x, dp_y,
+ * |dp| and (if |dp| > 0) a count of 1 over its box of four H x W float64 grids;
+ * a sequence's grids start from zero and are then added to the running totals
+ * (:89-92).  boxes: n x 4 int32 {x_start, x_end, y_start, y_end} (half open, as
+ * the slices at :84-88; empty boxes paint nothing), vals: n x 3 float64 {dp_x,
+ * dp_y, |dp|}, both in the reference's visiting order; per pixel the values are
+ * summed in that order, so the totals match the reference bit for bit.
+ * max_box_w / max_box_h: upper bounds of the box sides (they size the
+ * workspace).  depth, dp_x, dp_y, contrib: the running totals, updated in
+ * place (zero them before the first sequence). */
+size_t svamd_accumulate_boxes_workspace_bytes(int64_t n, int H, int W, int max_box_w, int max_box_h);
+int svamd_accumulate_boxes(const int32_t *boxes, const double *vals, int64_t n, int H, int W,
+                           int max_box_w, int max_box_h, double *depth, double *dp_x, double *dp_y,
+                           double *contrib, void *workspace, size_t workspace_bytes, void *stream);
+
+/* The same accumulation for the dense band scan's disparity map: window
+ * (wy, wx) of the nwy x nwx grid paints disp[wy][wx] (SVAMD_BAND_NO_MATCH counts
+ * as 0; dp_y is 0 throughout) over rows [wy*stride_y, wy*stride_y+win_h) and
+ * columns [wx, wx+win_w).  Sums of integers: exact. */
+size_t svamd_band_accumulate_workspace_bytes(int H, int W, int win_h, int stride_y);
+int svamd_band_accumulate(const int32_t *disp, int H, int W, int win_w, int win_h, int stride_y,
+                          double *depth, double *dp_x, double *contrib, void *workspace,
+                          size_t workspace_bytes, void *stream);
+
+/* test_image_comparison.py:95-98: contributions of 0 become infinity, then the
+ * three grids are divided by the contributions, in place. */
+int svamd_grid_average(double *depth, double *dp_x, double *dp_y, double *contrib, int64_t total,
+                       void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -274,3 +274,59 @@ def sequence_scan(left, right, scan_config, centre_tol=CENTRE_TOL):
                 cur[wid] = w
         stages.append(cur)
     return stages
+
+
+# ---- displacement grids (reference test_image_comparison.py:49-98) -------------------
+def accumulate_sequence(seq_results, shape):
+    '''The four grids one sequence paints: dp_x, dp_y, |dp| and a contribution
+    count over each window's box; only the deepest stage a window reached
+    contributes (reference test_image_comparison.py:61-88).'''
+    image_height, image_width = shape
+    dp_x_grid, dp_y_grid = np.zeros(shape), np.zeros(shape)
+    depth_grid, contributions = np.zeros(shape), np.zeros(shape)
+    for stage, windows in enumerate(seq_results):
+        for window_info in windows.values():
+            reached = len(window_info['stage_centres']) - 1
+            if reached > stage:
+                continue
+            x, y = window_info['stage_centres'][stage - 1 if reached < stage else stage]
+            magnitude = np.sqrt(window_info['dp_x'] ** 2 + window_info['dp_y'] ** 2)
+            x_window, y_window = window_info['stage_sizes'][stage]
+            box = (slice(int(max(y - y_window / 2, 0)), int(min(y + y_window / 2, image_height))),
+                   slice(int(max(x - x_window / 2, 0)), int(min(x + x_window / 2, image_width))))
+            dp_x_grid[box] += window_info['dp_x']
+            dp_y_grid[box] += window_info['dp_y']
+            depth_grid[box] += magnitude
+            if magnitude > 0:
+                contributions[box] += 1
+    return depth_grid, dp_x_grid, dp_y_grid, contributions
+
+
+def depth_grids(all_seq_results, shape):
+    '''Sum over sequences, then the average by contributions with 0 -> infinity
+    (reference test_image_comparison.py:89-98).  Returns (depth, dp_x, dp_y,
+    contributions).'''
+    totals = [np.zeros(shape) for _ in range(4)]
+    for seq_results in all_seq_results:
+        for total, grid in zip(totals, accumulate_sequence(seq_results, shape)):
+            total += grid
+    depth, dp_x, dp_y, contributions = totals
+    contributions[contributions == 0] = np.inf
+    return depth / contributions, dp_x / contributions, dp_y / contributions, contributions
+
+
+def band_depth_grids(disparity, shape, win_w, win_h, stride_y=1):
+    '''The same grids for a dense band scan's disparity map (one window per
+    origin, dp_y = 0), before the averaging.'''
+    depth, dp_x, contributions = np.zeros(shape), np.zeros(shape), np.zeros(shape)
+    for wy in range(disparity.shape[0]):
+        for wx in range(disparity.shape[1]):
+            d = int(disparity[wy, wx])
+            if d == -2 ** 31:
+                d = 0
+            box = (slice(wy * stride_y, wy * stride_y + win_h), slice(wx, wx + win_w))
+            dp_x[box] += d
+            depth[box] += abs(d)
+            if d != 0:
+                contributions[box] += 1
+    return depth, dp_x, contributions

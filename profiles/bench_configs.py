@@ -234,7 +234,60 @@ def config5():
          seconds=time.perf_counter() - t0)
 
 
+def config_grids():
+    '''Displacement-grid accumulation: the dense band scan's 4096x4096 disparity
+    map, and a box list shaped like a 25x25 / overlap 0.5 scan of a 4096x4096
+    pair (about 116k windows), device time.'''
+    import depth_grids
+    lib = nv.load_library()
+    H = W = 4096
+    rng = np.random.default_rng(3)
+    disp = nv.to_device(rng.integers(-128, 129, size=(H - 30, W - 30)).astype(np.int32))
+    totals = depth_grids.DepthGrids((H, W))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for it in range(4):
+        if it == 1:
+            e0.record()
+        totals.add_band_scan(disp, 31, 31)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 3
+    emit(config='N1', what='svamd_band_accumulate, 4066x4066 windows of 31x31 into 4096x4096 grids, device time',
+         device_ms=ms, windows_per_s=disp.numel() / ms * 1e3)
+    xs = np.arange(0, W, 12)
+    ys = np.arange(0, H, 12)
+    gx, gy = np.meshgrid(xs, ys)
+    boxes = np.stack([gx.ravel(), np.minimum(gx.ravel() + 25, W), gy.ravel(), np.minimum(gy.ravel() + 25, H)],
+                     axis=1).astype(np.int32)
+    values = rng.standard_normal((boxes.shape[0], 3))
+    values[:, 2] = np.hypot(values[:, 0], values[:, 1])
+    n = boxes.shape[0]
+    d_boxes, d_values = nv.to_device(boxes), nv.to_device(values)
+    ws = nv.workspace(lib.svamd_accumulate_boxes_workspace_bytes(n, H, W, 25, 25))
+    for it in range(4):
+        if it == 1:
+            e0.record()
+        nv.call('svamd_accumulate_boxes', nv.ptr(d_boxes), nv.ptr(d_values), n, H, W, 25, 25,
+                nv.ptr(totals.depth), nv.ptr(totals.dp_x), nv.ptr(totals.dp_y), nv.ptr(totals.contributions),
+                nv.ptr(ws), ws.numel(), nv.stream_ptr())
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 3
+    emit(config='N1', what=f'svamd_accumulate_boxes, {n} boxes of 25x25 into 4096x4096 grids, device time',
+         device_ms=ms, boxes_per_s=n / ms * 1e3)
+    t0 = time.perf_counter()
+    seq = [np.zeros((H, W)) for _ in range(4)]
+    for (bx0, bx1, by0, by1), (vx, vy, vm) in zip(boxes[:20000], values[:20000]):
+        seq[0][by0:by1, bx0:bx1] += vm
+        seq[1][by0:by1, bx0:bx1] += vx
+        seq[2][by0:by1, bx0:bx1] += vy
+        seq[3][by0:by1, bx0:bx1] += 1
+    dt = time.perf_counter() - t0
+    emit(config='N1', what='cpu numpy painting loop (the reference\'s form), 20000 of those boxes, 1 thread',
+         seconds=dt, boxes_per_s=20000 / dt)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['1', '1d', '2', '3', '4b', '5']
+    which = sys.argv[1:] or ['1', '1d', '2', '3', '4b', '5', 'n1']
     for c in which:
-        {'1': config1, '1d': config1_device, '2': config2, '3': config3, '4b': config4b, '5': config5}[c]()
+        {'1': config1, '1d': config1_device, '2': config2, 'n1': config_grids, '3': config3, '4b': config4b, '5': config5}[c]()

@@ -1,6 +1,7 @@
 '''Driver: runs every sequence of a scan config on a left/right image pair,
-accumulates the per-window displacements into full-resolution grids, averages
-them by the number of contributing windows and optionally saves / plots them.
+accumulates the per-window displacements into full-resolution grids (on the
+device, depth_grids.DepthGrids), averages them by the number of contributing
+windows and optionally saves / plots them.
 Counterpart of the reference's test_image_comparison.py with the same flags;
 --image_dir / --config_dir / --data_dir are additions.'''
 import json
@@ -10,33 +11,9 @@ from datetime import datetime
 import numpy as np
 from PIL import Image
 
+from depth_grids import DepthGrids
 from sv_image_comparison import sequence_scan, plot_sequence_output
 from utils import downsample
-
-
-def accumulate_sequence(seq_results, shape):
-    '''Paints dp_x, dp_y, |dp| and a contribution count over each window's box;
-    only the deepest stage a window reached contributes (reference
-    test_image_comparison.py:61-88).'''
-    image_height, image_width = shape
-    dp_x_grid, dp_y_grid = np.zeros(shape), np.zeros(shape)
-    depth_grid, contributions = np.zeros(shape), np.zeros(shape)
-    for stage, windows in enumerate(seq_results):
-        for window_info in windows.values():
-            reached = len(window_info['stage_centres']) - 1
-            if reached > stage:
-                continue
-            x, y = window_info['stage_centres'][stage - 1 if reached < stage else stage]
-            magnitude = np.sqrt(window_info['dp_x'] ** 2 + window_info['dp_y'] ** 2)
-            x_window, y_window = window_info['stage_sizes'][stage]
-            box = (slice(int(max(y - y_window / 2, 0)), int(min(y + y_window / 2, image_height))),
-                   slice(int(max(x - x_window / 2, 0)), int(min(x + x_window / 2, image_width))))
-            dp_x_grid[box] += window_info['dp_x']
-            dp_y_grid[box] += window_info['dp_y']
-            depth_grid[box] += magnitude
-            if magnitude > 0:
-                contributions[box] += 1
-    return depth_grid, dp_x_grid, dp_y_grid, contributions
 
 
 def calc_max_shift_magnitude(config):
@@ -71,7 +48,7 @@ def main():
             image = np.asarray(Image.open(f'{args.image_dir}/{side}_{args.images}.tiff').convert('L'))
             images.append(downsample(image, args.ds_factor))
         left_image, right_image = images
-        totals = [np.zeros(left_image.shape) for _ in range(4)]
+        totals = DepthGrids(left_image.shape)
         for i, seq_config in enumerate(config):
             start = datetime.now()
             seq_results = sequence_scan(left_image, right_image, seq_config)
@@ -80,14 +57,9 @@ def main():
                 plot_sequence_output(left_image, right_image, seq_results,
                                      max_shift_magnitude=calc_max_shift_magnitude(seq_config[0]),
                                      shift_plot_type=args.shift_plot_type)
-            for total, grid in zip(totals, accumulate_sequence(seq_results, left_image.shape)):
-                total += grid
-        total_depth_grid, total_dp_x_grid, total_dp_y_grid, total_contributions_grid = totals
+            totals.add_sequence(seq_results)
         # average by the number of windows that contributed to each pixel
-        total_contributions_grid[total_contributions_grid == 0] = np.inf
-        total_depth_grid = total_depth_grid / total_contributions_grid
-        total_dp_x_grid = total_dp_x_grid / total_contributions_grid
-        total_dp_y_grid = total_dp_y_grid / total_contributions_grid
+        total_depth_grid, total_dp_x_grid, total_dp_y_grid, total_contributions_grid = totals.average()
         if args.depth_output is not None:
             with open(f'{args.data_dir}/{args.depth_output}', 'w') as f:
                 json.dump({

@@ -330,6 +330,62 @@ def g8_dense_u8(ref):
     save('g8_dense_u8', left=left, right=right, config=np.array(json.dumps(cfg)), **out)
 
 
+def g10_depth_grids(ref):
+    '''The displacement grids the reference's stereo driver (test_image_comparison.py
+    main()) saves with --depth_output, for the cone pair and three configs.
+
+    The driver is run as it is, in a scratch directory that holds the images and
+    the config under the relative paths it expects, with two adjustments at its
+    edges: `downsample` (which needs scikit-image) is replaced in the driver's
+    namespace by the uint8 / 255 conversion that defines the scan's input in
+    these fixtures, and numpy's removed alias `np.Infinity` is restored.'''
+    import importlib
+    import shutil
+    import tempfile
+    from PIL import Image
+    if not hasattr(np, 'Infinity'):
+        np.Infinity = np.inf
+    drv = importlib.import_module('test_image_comparison')
+    drv.downsample = lambda image, factor: image / 255.0
+    d = np.load(os.path.join(OUT, 'g6_cone_images.npz'))
+    g9 = json.loads(str(np.load(os.path.join(OUT, 'g9_cone_multipass.npz'))['config']))
+    with open(f'{REF}/configs/scan_config.json') as f:
+        two_stage = json.load(f)
+    with open(f'{REF}/configs/scan_config_portal.json') as f:
+        portal = json.load(f)
+    arrays = {}
+    cwd = os.getcwd()
+    tmp = tempfile.mkdtemp()
+    try:
+        os.makedirs(f'{tmp}/images-p2-uncal')
+        os.makedirs(f'{tmp}/configs')
+        os.makedirs(f'{tmp}/depth-data')
+        Image.fromarray(d['left'], 'L').save(f'{tmp}/images-p2-uncal/left_cone.tiff')
+        Image.fromarray(d['right'], 'L').save(f'{tmp}/images-p2-uncal/right_cone.tiff')
+        os.chdir(tmp)
+        for tag, cfg in (('scan_config', two_stage), ('portal', portal), ('multipass', g9)):
+            with open('configs/cfg.json', 'w') as f:
+                json.dump(cfg, f)
+            argv = sys.argv
+            sys.argv = ['test_image_comparison.py', '--images', 'cone', '--config', 'cfg.json',
+                        '--depth_output', 'out.json', '--hide_depth']
+            try:
+                quiet(drv.main)
+            finally:
+                sys.argv = argv
+            with open('depth-data/out.json') as f:
+                saved = json.load(f)
+            arrays[f'{tag}_config'] = np.array(json.dumps(cfg))
+            for key in ('depth_grid', 'dp_x_grid', 'dp_y_grid', 'contributions_grid'):
+                arrays[f'{tag}_{key}'] = np.array(saved[key], dtype=np.float64)
+            print(f'    {tag}: depth max {np.max(arrays[tag + "_depth_grid"]):.4f}, '
+                  f'painted {np.isfinite(arrays[tag + "_contributions_grid"]).sum()} px')
+    finally:
+        os.chdir(cwd)
+        shutil.rmtree(tmp)
+    save('g10_cone_depth_grids', **arrays)
+
+
 GROUPS = {
     'g1': g1_spatial_template_region,
     'g2': g2_spatial_nan_template,
@@ -340,6 +396,7 @@ GROUPS = {
     'g7': g7_dense,
     'g8': g8_dense_u8,
     'g9': g9_multipass,
+    'g10': g10_depth_grids,
 }
 
 

@@ -158,3 +158,18 @@ def test_g9_multipass(oracle):
 def test_g8_dense_u8(oracle):
     g = golden('g8_dense_u8')
     check_scan(oracle, g, g['left'] / 255.0, g['right'] / 255.0)
+
+
+# ---- displacement grids ----------------------------------------------------------------
+@pytest.mark.parametrize('tag', ['scan_config', 'portal', 'multipass'])
+def test_g10_depth_grids(oracle, tag):
+    '''The grids the reference's stereo driver saves (sum over sequences, average
+    by contributions) from the oracle's scan results: identical, bit for bit.'''
+    g = golden('g10_cone_depth_grids')
+    im = golden('g6_cone_images')
+    left, right = im['left'] / 255.0, im['right'] / 255.0
+    cfg = json.loads(str(g[f'{tag}_config']))
+    results = [oracle.sequence_scan(left, right, seq) for seq in cfg]
+    grids = oracle.depth_grids(results, left.shape)
+    for got, key in zip(grids, ('depth_grid', 'dp_x_grid', 'dp_y_grid', 'contributions_grid')):
+        assert np.array_equal(got, g[f'{tag}_{key}']), key

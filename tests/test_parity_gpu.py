@@ -483,6 +483,74 @@ def test_fft_route_1024_shapes_and_offsets(mods, oracle):
         assert_surface_close(got, want, SURFACE_TOL, f'fft1024 {tshape}')
 
 
+# ---- displacement grids ------------------------------------------------------------------
+@pytest.mark.parametrize('tag', ['scan_config', 'portal', 'multipass'])
+def test_g10_depth_grids(mods, tag):
+    '''Scan + grid accumulation on the device against the grids the reference's
+    stereo driver saved: identical, bit for bit.'''
+    import depth_grids
+    g = golden('g10_cone_depth_grids')
+    im = golden('g6_cone_images')
+    left, right = im['left'] / 255.0, im['right'] / 255.0
+    totals = depth_grids.DepthGrids(left.shape)
+    for seq in json.loads(str(g[f'{tag}_config'])):
+        totals.add_sequence(quiet(mods['v'].sequence_scan, left, right, seq))
+    for got, key in zip(totals.average(), ('depth_grid', 'dp_x_grid', 'dp_y_grid', 'contributions_grid')):
+        assert np.array_equal(got, g[f'{tag}_{key}']), key
+
+
+@pytest.mark.parametrize('shape,n,max_side', [((70, 90), 500, 40), ((300, 520), 20000, 64), ((33, 700), 3000, 300),
+                                              ((600, 40), 1, 700)])
+def test_accumulate_boxes_random(mods, shape, n, max_side):
+    '''Random overlapping boxes with irrational values: the device sums every
+    pixel's boxes in list order, so it equals the sequential numpy painting
+    exactly; two calls accumulate into the same totals.'''
+    import depth_grids
+    rng = np.random.default_rng(n)
+    h, w = shape
+    x0 = rng.integers(-10, w, size=n)
+    y0 = rng.integers(-10, h, size=n)
+    boxes = np.stack([np.maximum(x0, 0), np.minimum(x0 + rng.integers(0, max_side, size=n), w),
+                      np.maximum(y0, 0), np.minimum(y0 + rng.integers(0, max_side, size=n), h)], axis=1)
+    values = rng.standard_normal((n, 3))
+    values[:, 2] = np.abs(values[:, 2]) * (rng.random(n) < 0.7)
+    want = [np.zeros(shape) for _ in range(4)]
+    totals = depth_grids.DepthGrids(shape)
+    for part in (slice(0, n // 2), slice(n // 2, n)):
+        seq = [np.zeros(shape) for _ in range(4)]
+        for (bx0, bx1, by0, by1), (vx, vy, vm) in zip(boxes[part], values[part]):
+            if bx0 < bx1 and by0 < by1:
+                seq[0][by0:by1, bx0:bx1] += vm
+                seq[1][by0:by1, bx0:bx1] += vx
+                seq[2][by0:by1, bx0:bx1] += vy
+                if vm > 0:
+                    seq[3][by0:by1, bx0:bx1] += 1
+        for t, q in zip(want, seq):
+            t += q
+        totals.add_boxes(boxes[part], values[part])
+    got = [t.cpu().numpy() for t in (totals.depth, totals.dp_x, totals.dp_y, totals.contributions)]
+    for a, b, name in zip(got, want, ('depth', 'dp_x', 'dp_y', 'contributions')):
+        assert np.array_equal(a, b), name
+
+
+@pytest.mark.parametrize('win,h,w,md,stride', [(31, 70, 300, 24, 1), (15, 64, 90, 10, 2), (7, 40, 50, 5, 3)])
+def test_band_accumulate_vs_oracle(mods, oracle, win, h, w, md, stride):
+    import depth_grids
+    left, right = synthetic_pair(h, w, win + md, min(md, 12))
+    left[5:5 + win, 3:3 + win] = 200                     # a constant window: no match
+    disp, _ = mods['b'].band_scan(left, right, win, win, md, row_stride=stride)
+    totals = depth_grids.DepthGrids((h, w))
+    totals.add_band_scan(disp, win, win, stride)
+    depth, dp_x, contributions = oracle.band_depth_grids(disp, (h, w), win, win, stride)
+    assert np.array_equal(totals.depth.cpu().numpy(), depth)
+    assert np.array_equal(totals.dp_x.cpu().numpy(), dp_x)
+    assert np.array_equal(totals.contributions.cpu().numpy(), contributions)
+    assert not totals.dp_y.any()
+    avg = totals.average()
+    contributions[contributions == 0] = np.inf
+    assert np.array_equal(avg[0], depth / contributions) and np.array_equal(avg[3], contributions)
+
+
 # ---- driver scripts --------------------------------------------------------------------
 def run_driver(module, argv, monkeypatch, capsys):
     import importlib
@@ -538,3 +606,6 @@ def test_driver_image_comparison(mods, tmp_path, monkeypatch, capsys):
     want = g['seq0_stage0_windows']
     moved = want[(want[:, 5] != 0) | (want[:, 6] != 0)]
     assert len(moved) == 38 and np.count_nonzero(dp_x) > 0
+    ref = golden('g10_cone_depth_grids')
+    for key in ('depth_grid', 'dp_x_grid', 'dp_y_grid', 'contributions_grid'):
+        assert np.array_equal(np.array(saved[key]), ref[f'scan_config_{key}']), key
