@@ -541,8 +541,14 @@ fft_row_sums_kernel(const double *__restrict__ row_sums, int H, FftStats *__rest
     }
 }
 
-// pass 1, W = 1024: one wavefront per image row, four rows per workgroup.  Also
-// produces each row's exact sums of (x - centre) and (x - centre)^2 of both arrays.
+// pass 1, W = 1024: a wavefront transforms F1K_ROWS_PER_WAVE consecutive image rows,
+// one at a time, with the next row's pixels already on their way while the current
+// row is transformed (a wavefront that loads, transforms and stores a single row
+// spends most of its life waiting for memory).  Four wavefronts per workgroup.
+// Also produces each row's exact sums of (x - centre) and (x - centre)^2 of both
+// arrays.
+constexpr int F1K_ROWS_PER_WAVE = 4;
+
 __global__ void __launch_bounds__(256)
 f1k_rows_forward_kernel(const float *__restrict__ t, int th, int tw_, const float *__restrict__ r, int H,
                         const FftStats *__restrict__ stats, double *__restrict__ row_sums,
@@ -551,65 +557,80 @@ f1k_rows_forward_kernel(const float *__restrict__ t, int th, int tw_, const floa
 {
     __shared__ float2 lds[4 * F1K_LDS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int y = blockIdx.x * 4 + wave, pair = blockIdx.y;
-    if (y >= H)
+    const int y_first = (blockIdx.x * 4 + wave) * F1K_ROWS_PER_WAVE, pair = blockIdx.y;
+    if (y_first >= H)
         return;
+    const int y_end = min(y_first + F1K_ROWS_PER_WAVE, H);
     float2 *x = lds + wave * F1K_LDS;
     const float *tbase = t + (int64_t)pair * th * tw_;
     const float *rbase = r + (int64_t)pair * H * F1K;
     const float tc = stats[pair].t_centre, rc = stats[pair].r_centre;
-    const float *trow = tbase + (int64_t)y * tw_;
-    const float *rrow = rbase + (int64_t)y * F1K;
-    const bool trow_in = y < min(th, H);
-    const int mw = min(tw_, F1K);
-    float2 v[16];
-    // per-lane partial sums of 16 centred values fit float32 comfortably; lanes and
-    // rows are combined in float64
-    float fts = 0.f, ftq = 0.f, frs = 0.f, frq = 0.f;
+    const int mw = min(tw_, F1K), mh = min(th, H);
+
+    float tn[16], rn[16];           // the next row, raw
+    auto fetch = [&](int y) {
+        const float *trow = tbase + (int64_t)y * tw_;
+        const float *rrow = rbase + (int64_t)y * F1K;
+        const bool trow_in = y < mh;
 #pragma unroll
-    for (int m = 0; m < 16; ++m) {
-        const int xx = lane + 64 * m;
-        const float tv = (trow_in && xx < mw) ? trow[xx] - tc : 0.0f;
-        const float rv = rrow[xx] - rc;
-        v[m] = make_float2(tv, rv);
-        fts += tv;
-        ftq = fmaf(tv, tv, ftq);
-        frs += rv;
-        frq = fmaf(rv, rv, frq);
-    }
-    double ts = fts, tq = ftq, rs = frs, rq = frq;
-    // template statistics cover the whole template: add what the crop to the
-    // region's shape left out (columns beyond W, rows beyond H)
-    for (int yy = y; yy < th; yy += H)
-        for (int xx = (yy == y && trow_in ? mw : 0) + lane; xx < tw_; xx += 64) {
-            const double d = (double)(tbase[(int64_t)yy * tw_ + xx] - tc);
-            ts += d;
-            tq += d * d;
+        for (int m = 0; m < 16; ++m) {
+            const int xx = lane + 64 * m;
+            tn[m] = (trow_in && xx < mw) ? trow[xx] : tc;
+            rn[m] = rrow[xx];
         }
-    ts = wave_sum(ts);
-    tq = wave_sum(tq);
-    rs = wave_sum(rs);
-    rq = wave_sum(rq);
-    if (lane == 0)                  // per-row partial sums; fft_row_sums_kernel adds them up
-        reinterpret_cast<double4 *>(row_sums)[(int64_t)pair * H + y] = make_double4(ts, tq, rs, rq);
-    f1k_forward(v, x, twiddle, lane);
+    };
+    fetch(y_first);
+    for (int y = y_first; y < y_end; ++y) {
+        float2 v[16];
+        // per-lane partial sums of 16 centred values fit float32 comfortably; lanes and
+        // rows are combined in float64
+        float fts = 0.f, ftq = 0.f, frs = 0.f, frq = 0.f;
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            x[f1k_idx(4 * (lane + 64 * u) + e)] = v[4 * u + e];
-    __builtin_amdgcn_wave_barrier();
-    float2 *ot = spec_t + ((int64_t)pair * H + y) * hp;
-    float2 *orr = spec_r + ((int64_t)pair * H + y) * hp;
-#pragma unroll
-    for (int i = 0; i <= 8; ++i) {
-        const int k = lane + 64 * i;
-        if (k <= F1K / 2) {
-            const float2 zk = x[f1k_idx(digit_reverse(k, 10))];
-            const float2 zm = x[f1k_idx(digit_reverse((F1K - k) & (F1K - 1), 10))];
-            ot[k] = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
-            orr[k] = make_float2(0.5f * (zk.y + zm.y), 0.5f * (zm.x - zk.x));
+        for (int m = 0; m < 16; ++m) {
+            const float tv = tn[m] - tc, rv = rn[m] - rc;
+            v[m] = make_float2(tv, rv);
+            fts += tv;
+            ftq = fmaf(tv, tv, ftq);
+            frs += rv;
+            frq = fmaf(rv, rv, frq);
         }
+        if (y + 1 < y_end)
+            fetch(y + 1);
+        double ts = fts, tq = ftq, rs = frs, rq = frq;
+        // template statistics cover the whole template: add what the crop to the
+        // region's shape left out (columns beyond W, rows beyond H)
+        for (int yy = y; yy < th; yy += H)
+            for (int xx = (yy == y && y < mh ? mw : 0) + lane; xx < tw_; xx += 64) {
+                const double d = (double)(tbase[(int64_t)yy * tw_ + xx] - tc);
+                ts += d;
+                tq += d * d;
+            }
+        ts = wave_sum(ts);
+        tq = wave_sum(tq);
+        rs = wave_sum(rs);
+        rq = wave_sum(rq);
+        if (lane == 0)                  // per-row partial sums; fft_row_sums_kernel adds them up
+            reinterpret_cast<double4 *>(row_sums)[(int64_t)pair * H + y] = make_double4(ts, tq, rs, rq);
+        f1k_forward(v, x, twiddle, lane);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                x[f1k_idx(4 * (lane + 64 * u) + e)] = v[4 * u + e];
+        __builtin_amdgcn_wave_barrier();
+        float2 *ot = spec_t + ((int64_t)pair * H + y) * hp;
+        float2 *orr = spec_r + ((int64_t)pair * H + y) * hp;
+#pragma unroll
+        for (int i = 0; i <= 8; ++i) {
+            const int k = lane + 64 * i;
+            if (k <= F1K / 2) {
+                const float2 zk = x[f1k_idx(digit_reverse(k, 10))];
+                const float2 zm = x[f1k_idx(digit_reverse((F1K - k) & (F1K - 1), 10))];
+                ot[k] = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
+                orr[k] = make_float2(0.5f * (zk.y + zm.y), 0.5f * (zm.x - zk.x));
+            }
+        }
+        __builtin_amdgcn_wave_barrier();    // the next row reuses x
     }
 }
 
@@ -864,7 +885,7 @@ extern "C" int svamd_xcorr2d_fft(const float *tmpl, int th, int tw, const float 
         SV_LAUNCH_CHECK();
     }
     if (fast) {
-        hipLaunchKernelGGL(f1k_rows_forward_kernel, dim3(H / 4, batch), dim3(256), 0, st, tmpl, th, tw, region, H,
+        hipLaunchKernelGGL(f1k_rows_forward_kernel, dim3((H + 4 * F1K_ROWS_PER_WAVE - 1) / (4 * F1K_ROWS_PER_WAVE), batch), dim3(256), 0, st, tmpl, th, tw, region, H,
                            stats, row_sums, tw_w, spec_t, spec_r, hp);
         SV_LAUNCH_CHECK();
         hipLaunchKernelGGL(fft_row_sums_kernel, dim3(batch), dim3(1024), 0, st, row_sums, H, stats);
