@@ -212,6 +212,15 @@ int svamd_band_accumulate(const int32_t *disp, int H, int W, int win_w, int win_
 int svamd_grid_average(double *depth, double *dp_x, double *dp_y, double *contrib, int64_t total,
                        void *stream);
 
+/* ---- calibration peak finder: local maxima of a correlation surface -------------
+ * sv_calibration.py:125-129.  mask[y][x] = 1 where data equals the maximum of its
+ * size x size neighbourhood (scipy.ndimage.maximum_filter's window and reflected
+ * borders) and that maximum exceeds the neighbourhood's minimum by more than
+ * `threshold`, else 0.  data: H x W float64 without NaNs; mask: H x W uint8. */
+size_t svamd_peak_mask_workspace_bytes(int H, int W);
+int svamd_peak_mask(const double *data, int H, int W, int size, double threshold, uint8_t *mask,
+                    void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

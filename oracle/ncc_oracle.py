@@ -330,3 +330,61 @@ def band_depth_grids(disparity, shape, win_w, win_h, stride_y=1):
             if d != 0:
                 contributions[box] += 1
     return depth, dp_x, contributions
+
+
+# ---- calibration peak finder (reference sv_calibration.py:115-141) ----------------------
+def _neighbourhood_extreme(data, size, fn):
+    '''scipy.ndimage maximum_filter / minimum_filter with a scalar size: window
+    offsets -(size // 2) .. size - size // 2 - 1, borders reflected about the edge.'''
+    lo = size // 2
+    hi = size - lo - 1
+    padded = np.pad(data, ((lo, hi), (lo, hi)), mode='symmetric')
+    out = None
+    for dy in range(size):
+        for dx in range(size):
+            part = padded[dy:dy + data.shape[0], dx:dx + data.shape[1]]
+            out = part.copy() if out is None else fn(out, part)
+    return out
+
+
+def peak_mask(data, size, threshold):
+    data = _f64(data)
+    data_max = _neighbourhood_extreme(data, size, np.maximum)
+    data_min = _neighbourhood_extreme(data, size, np.minimum)
+    return (data == data_max) & ((data_max - data_min) > threshold)
+
+
+def _label_boxes(mask):
+    '''Bounding boxes (y0, y1, x0, x1; inclusive) of the 4-connected groups of a
+    mask, ordered by each group's first pixel in raster order (the order of
+    scipy.ndimage.label + find_objects).'''
+    h, w = mask.shape
+    seen = np.zeros_like(mask, dtype=bool)
+    boxes = []
+    for y, x in zip(*np.nonzero(mask)):
+        if seen[y, x]:
+            continue
+        stack = [(y, x)]
+        seen[y, x] = True
+        y0 = y1 = y
+        x0 = x1 = x
+        while stack:
+            cy, cx = stack.pop()
+            y0, y1, x0, x1 = min(y0, cy), max(y1, cy), min(x0, cx), max(x1, cx)
+            for ny, nx in ((cy - 1, cx), (cy + 1, cx), (cy, cx - 1), (cy, cx + 1)):
+                if 0 <= ny < h and 0 <= nx < w and mask[ny, nx] and not seen[ny, nx]:
+                    seen[ny, nx] = True
+                    stack.append((ny, nx))
+        boxes.append((y0, y1, x0, x1))
+    return boxes
+
+
+def find_peaks(region, neighborhood_size, threshold):
+    grid = np.linspace(-5, 5, 101)
+    x_grid, y_grid = np.meshgrid(grid, grid)
+    template = np.exp(-(x_grid ** 2 + y_grid ** 2))
+    data = cross_correlate_2d_spectral(template, region)
+    boxes = _label_boxes(peak_mask(data, neighborhood_size, threshold))
+    x = np.array([(b[2] + b[3]) / 2 for b in boxes]) + template.shape[1] / 2
+    y = np.array([(b[0] + b[1]) / 2 for b in boxes]) + template.shape[0] / 2
+    return x, y

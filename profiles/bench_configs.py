@@ -287,7 +287,33 @@ def config_grids():
          seconds=dt, boxes_per_s=20000 / dt)
 
 
+def config_peaks():
+    '''Calibration peak finder on a synthetic 1600x2400 dot-grid image (101x101
+    Gaussian template, 10x10 neighbourhoods), wall clock of find_peaks.'''
+    import sv_calibration
+    rng = np.random.default_rng(7)
+    h, w = 1600, 2400
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = 20 + 6 * rng.standard_normal((h, w))
+    for gy in range(100, h - 80, 140):
+        for gx in range(100, w - 80, 140):
+            cy, cx = gy + rng.uniform(-6, 6), gx + rng.uniform(-6, 6)
+            ys, xs = slice(int(cy) - 30, int(cy) + 31), slice(int(cx) - 30, int(cx) + 31)
+            img[ys, xs] += 200 * np.exp(-((yy[ys, xs] - cy) ** 2 + (xx[ys, xs] - cx) ** 2) / 50.0)
+    img = np.clip(np.rint(img), 0, 255).astype(np.uint8)
+    dt, (x, y) = timed(sv_calibration.find_peaks, img, 10, 0.2)
+    emit(config='N2', what='find_peaks, 1600x2400 uint8 image, 101x101 template (call incl. transfers)',
+         seconds=dt, peaks=len(x), tflops_equiv=2.0 * 101 * 101 * h * w / dt / 1e12)
+    from oracle import ncc_oracle
+    t0 = time.perf_counter()
+    grid = np.linspace(-5, 5, 101)
+    xg, yg = np.meshgrid(grid, grid)
+    ncc_oracle.cross_correlate_2d_spectral_fft(np.exp(-(xg ** 2 + yg ** 2)), img.astype(np.float64))
+    emit(config='N2', what='cpu numpy FFT correlation of the same pair alone (1 thread)',
+         seconds=time.perf_counter() - t0)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['1', '1d', '2', '3', '4b', '5', 'n1']
+    which = sys.argv[1:] or ['1', '1d', '2', '3', '4b', '5', 'n1', 'n2']
     for c in which:
-        {'1': config1, '1d': config1_device, '2': config2, 'n1': config_grids, '3': config3, '4b': config4b, '5': config5}[c]()
+        {'1': config1, '1d': config1_device, '2': config2, 'n1': config_grids, 'n2': config_peaks, '3': config3, '4b': config4b, '5': config5}[c]()

@@ -56,6 +56,8 @@ PROTOTYPES = {
     'svamd_band_accumulate_workspace_bytes': (_sz, [_i, _i, _i, _i]),
     'svamd_band_accumulate': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     'svamd_grid_average': (_i, [_vp, _vp, _vp, _vp, _i64, _vp]),
+    'svamd_peak_mask_workspace_bytes': (_sz, [_i, _i]),
+    'svamd_peak_mask': (_i, [_vp, _i, _i, _i, _d, _vp, _vp, _sz, _vp]),
 }
 
 _lib = None

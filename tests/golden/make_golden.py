@@ -386,6 +386,36 @@ def g10_depth_grids(ref):
     save('g10_cone_depth_grids', **arrays)
 
 
+def dot_grid_image(h, w, seed):
+    '''A synthetic calibration image: bright Gaussian dots on a jittered grid over
+    a noisy dark background, uint8.'''
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = 20 + 6 * rng.standard_normal((h, w))
+    for gy in range(70, h - 60, 60):
+        for gx in range(80, w - 60, 65):
+            cy, cx = gy + rng.uniform(-6, 6), gx + rng.uniform(-6, 6)
+            img += 200 * np.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / (2 * 5.0 ** 2))
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+def g11_find_peaks(ref):
+    '''The reference's calibration peak finder (sv_calibration.find_peaks) on two
+    synthetic dot-grid images (its own calibration images are not in the tree).'''
+    import importlib
+    cal = importlib.import_module('sv_calibration')
+    arrays = {}
+    for tag, (h, w, seed) in (('a', (330, 470, 11)), ('b', (256, 512, 12))):
+        img = dot_grid_image(h, w, seed)
+        with np.errstate(all='ignore'):
+            x, y = cal.find_peaks(img, neighborhood_size=10, threshold=0.2)
+        print(f'    image {tag}: {len(x)} peaks')
+        arrays[f'{tag}_image'] = img
+        arrays[f'{tag}_x'] = np.asarray(x, dtype=np.float64)
+        arrays[f'{tag}_y'] = np.asarray(y, dtype=np.float64)
+    save('g11_find_peaks', **arrays)
+
+
 GROUPS = {
     'g1': g1_spatial_template_region,
     'g2': g2_spatial_nan_template,
@@ -397,6 +427,7 @@ GROUPS = {
     'g8': g8_dense_u8,
     'g9': g9_multipass,
     'g10': g10_depth_grids,
+    'g11': g11_find_peaks,
 }
 
 

@@ -173,3 +173,11 @@ def test_g10_depth_grids(oracle, tag):
     grids = oracle.depth_grids(results, left.shape)
     for got, key in zip(grids, ('depth_grid', 'dp_x_grid', 'dp_y_grid', 'contributions_grid')):
         assert np.array_equal(got, g[f'{tag}_{key}']), key
+
+
+# ---- calibration peak finder -----------------------------------------------------------
+@pytest.mark.parametrize('tag', ['a', 'b'])
+def test_g11_find_peaks(oracle, tag):
+    g = golden('g11_find_peaks')
+    x, y = oracle.find_peaks(g[f'{tag}_image'], 10, 0.2)
+    assert np.array_equal(x, g[f'{tag}_x']) and np.array_equal(y, g[f'{tag}_y'])

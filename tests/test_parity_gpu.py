@@ -551,6 +551,32 @@ def test_band_accumulate_vs_oracle(mods, oracle, win, h, w, md, stride):
     assert np.array_equal(avg[0], depth / contributions) and np.array_equal(avg[3], contributions)
 
 
+# ---- calibration peak finder ---------------------------------------------------------------
+@pytest.mark.parametrize('tag', ['a', 'b'])
+def test_g11_find_peaks(mods, tag):
+    '''Peak positions of the reference's find_peaks on synthetic dot grids: the
+    same peaks at the same positions.'''
+    import sv_calibration
+    g = golden('g11_find_peaks')
+    x, y = sv_calibration.find_peaks(g[f'{tag}_image'], neighborhood_size=10, threshold=0.2)
+    assert np.array_equal(x, g[f'{tag}_x']) and np.array_equal(y, g[f'{tag}_y'])
+
+
+@pytest.mark.parametrize('shape,size,thr', [((40, 56), 10, 0.2), ((33, 70), 3, 0.5), ((64, 64), 7, 0.0),
+                                            ((5, 9), 10, 0.1)])
+def test_peak_mask_vs_oracle_and_scipy(mods, oracle, shape, size, thr):
+    import sv_calibration
+    from scipy import ndimage
+    rng = np.random.default_rng(size)
+    data = rng.random(shape)
+    if shape[0] > 14:
+        data[10:14, 20:24] = 2.0                     # a plateau of equal maxima
+    got = sv_calibration.peak_mask(data, size, thr)
+    assert np.array_equal(got, oracle.peak_mask(data, size, thr))
+    dmax, dmin = ndimage.maximum_filter(data, size), ndimage.minimum_filter(data, size)
+    assert np.array_equal(got, (data == dmax) & ((dmax - dmin) > thr))
+
+
 # ---- driver scripts --------------------------------------------------------------------
 def run_driver(module, argv, monkeypatch, capsys):
     import importlib
