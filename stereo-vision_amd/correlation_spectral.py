@@ -99,7 +99,16 @@ def cross_correlate_2d_spectral(orig_template: np.ndarray, orig_region: np.ndarr
     if overlap * FFT_MIN_COVER >= rh * rw and nv.load_library().svamd_fft_supported(rh, rw):
         # power-of-two region: batched LDS FFT route with a batch of one
         return cross_correlate_2d_spectral_batched(template[None], region[None], np.float64)[0]
+    return spectral_surface_on_device(template, region).cpu().numpy()
 
+
+def spectral_surface_on_device(template, region):
+    '''cross_correlate_2d_spectral's surface through the sliding kernel, left on
+    the device as a float64 tensor (for callers that keep working on it there).'''
+    template = np.asarray(template)
+    region = np.asarray(region)
+    th, tw = template.shape
+    rh, rw = region.shape
     torch = nv.torch_cuda()
     t = nv.as_image(template)
     r = nv.as_image(region)
@@ -110,4 +119,4 @@ def cross_correlate_2d_spectral(orig_template: np.ndarray, orig_region: np.ndarr
     nv.call('svamd_cross_correlate_2d_spectral', nv.ptr(d_t), nv.dtype_code(t), th, tw,
             nv.ptr(d_r), nv.dtype_code(r), rh, rw, float(MIN_ST_DEV), float(MIN_MEAN_DIFF),
             nv.ptr(out), nv.ptr(ws), ws.numel(), nv.stream_ptr())
-    return out.cpu().numpy()
+    return out

@@ -8,7 +8,7 @@ import numpy as np
 from scipy import ndimage
 
 import _native as nv
-from correlation_spectral import cross_correlate_2d_spectral
+from correlation_spectral import spectral_surface_on_device
 
 
 def gaussian(x, y):
@@ -20,11 +20,13 @@ def gaussian(x, y):
 def peak_mask(data, neighborhood_size, threshold):
     '''Boolean mask of the pixels that equal their neighbourhood's maximum where
     that maximum exceeds the neighbourhood's minimum by more than `threshold`
-    (reference sv_calibration.py:125-129).'''
+    (reference sv_calibration.py:125-129).  data: host array or device tensor.'''
     torch = nv.torch_cuda()
-    data = np.ascontiguousarray(data, dtype=np.float64)
-    h, w = data.shape
-    d_data = nv.to_device(data)
+    if isinstance(data, torch.Tensor):
+        d_data = data.to(device='cuda', dtype=torch.float64).contiguous()
+    else:
+        d_data = nv.to_device(np.ascontiguousarray(data, dtype=np.float64))
+    h, w = d_data.shape
     mask = nv.empty((h, w), torch.uint8)
     ws = nv.workspace(nv.load_library().svamd_peak_mask_workspace_bytes(h, w))
     nv.call('svamd_peak_mask', nv.ptr(d_data), h, w, int(neighborhood_size), float(threshold), nv.ptr(mask),
@@ -39,7 +41,7 @@ def find_peaks(region, neighborhood_size, threshold):
     (reference sv_calibration.py:115-141).'''
     x_grid, y_grid = np.meshgrid(np.linspace(-5, 5, 101), np.linspace(-5, 5, 101))
     template = gaussian(x_grid, y_grid)
-    data = cross_correlate_2d_spectral(template, region)
+    data = spectral_surface_on_device(template, region)      # stays on the device
     maxima = peak_mask(data, neighborhood_size, threshold)
     labeled, num_objects = ndimage.label(maxima)
     slices = ndimage.find_objects(labeled)
