@@ -552,12 +552,16 @@ constexpr int F1K_ROWS_PER_WAVE = 4;
 __global__ void __launch_bounds__(256)
 f1k_rows_forward_kernel(const float *__restrict__ t, int th, int tw_, const float *__restrict__ r, int H,
                         const FftStats *__restrict__ stats, double *__restrict__ row_sums,
-                        const float2 *__restrict__ twiddle, float2 *__restrict__ spec_t,
+                        const float2 *__restrict__ twiddle_table, float2 *__restrict__ spec_t,
                         float2 *__restrict__ spec_r, int hp)
 {
     __shared__ float2 lds[4 * F1K_LDS];
+    __shared__ float2 twiddle[F1K];                 // LDS copy: gathered reads stay off the memory pipeline
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int y_first = (blockIdx.x * 4 + wave) * F1K_ROWS_PER_WAVE, pair = blockIdx.y;
+    for (int i = threadIdx.x; i < F1K; i += 256)
+        twiddle[i] = twiddle_table[i];
+    __syncthreads();
     if (y_first >= H)
         return;
     const int y_end = min(y_first + F1K_ROWS_PER_WAVE, H);
@@ -634,11 +638,21 @@ f1k_rows_forward_kernel(const float *__restrict__ t, int th, int tw_, const floa
     }
 }
 
-// pass 2, H = 1024: a tile of 8 spectrum columns; wavefront c transforms column c of
-// T (kept in registers), then column c of R, multiplies and transforms back.  The
-// R tile is fetched into registers before the T transform starts, so its memory
-// latency is covered by arithmetic.
-constexpr int F1K_TILE = 8;
+// pass 2, H = 1024: a tile of F1K_TILE spectrum columns; wavefront c transforms
+// column c of T (kept in registers), then column c of R, multiplies and transforms
+// back.  The R tile is fetched into registers before the T transform starts, so its
+// memory latency is covered by arithmetic.  Tiles of 4 columns (32-byte row pieces,
+// four workgroups of one XCD share each 128-byte line through its L2) in workgroups
+// of 4 wavefronts measured faster than tiles of 8 in workgroups of 8: the phases
+// of independent small workgroups on a CU overlap where one large workgroup waits
+// at its barriers.
+#ifndef SV_F1K_TILE
+#define SV_F1K_TILE 4
+#endif
+#ifndef SV_F1K_MINWAVES
+#define SV_F1K_MINWAVES 4
+#endif
+constexpr int F1K_TILE = SV_F1K_TILE;
 constexpr int F1K_COL = F1K_LDS + 2;              // column stride in LDS (bank spread for the transpose)
 constexpr int F1K_QUADS = F1K * (F1K_TILE / 2) / (64 * F1K_TILE);   // 16-byte pieces per lane and tile
 
@@ -672,23 +686,31 @@ __device__ __forceinline__ void f1k_tile_scatter(const float4 (&q)[F1K_QUADS], f
     }
 }
 
-// Persistent workgroups: each loops over (pair, tile) work items and always has the
-// next tile's memory reads in flight while it transforms the current one.
-// 8 wavefronts of up to 256 registers per lane: one workgroup per CU (the transform
-// of T stays in registers while R is transformed, and a tile prefetch is in flight)
-__global__ void __launch_bounds__(64 * F1K_TILE)
+// Workgroups loop over (pair, tile) work items and always have the next tile's
+// memory reads in flight while they transform the current one (the transform of T
+// stays in registers while R is transformed, and a tile prefetch is in flight:
+// about 210 registers per lane, two wavefronts per SIMD).
+__global__ void __launch_bounds__(64 * F1K_TILE, SV_F1K_MINWAVES)
 f1k_cols_fused_kernel(float2 *__restrict__ spec_t, const float2 *__restrict__ spec_r, int ncols, int hp,
-                      int tiles_per_pair, int total_tiles, const float2 *__restrict__ twiddle)
+                      int tiles_per_pair, int total_tiles, const float2 *__restrict__ twiddle_table)
 {
     __shared__ float2 tile[F1K_TILE * F1K_COL];
+    __shared__ float2 twiddle[F1K];                 // LDS copy: gathered reads stay off the memory pipeline
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float2 *x = tile + wave * F1K_COL;
-    // Two neighbouring tiles share every 128-byte line of a spectrum row.  Workgroups
-    // b and b + 8 run on the same XCD (round-robin dispatch), so they are given
-    // neighbouring work items: the second one finds the lines in that XCD's L2.
+    for (int i = threadIdx.x; i < F1K; i += 64 * F1K_TILE)
+        twiddle[i] = twiddle_table[i];
+    // Neighbouring tiles share every 128-byte line of a spectrum row.  Workgroups
+    // b, b + 8, b + 16, ... run on the same XCD (round-robin dispatch), so they are given
+    // neighbouring work items: the later ones find the lines in that XCD's L2.
     int first = blockIdx.x;
-    if (first < (int)(gridDim.x & ~15u))
-        first = (first & ~15) + ((first & 7) << 1) + ((first >> 3) & 1);
+    if (F1K_TILE == 8) {
+        if (first < (int)(gridDim.x & ~15u))
+            first = (first & ~15) + ((first & 7) << 1) + ((first >> 3) & 1);
+    } else {
+        if (first < (int)(gridDim.x & ~31u))
+            first = (first & ~31) + ((first & 7) << 2) + ((first >> 3) & 3);
+    }
 
     float4 q[F1K_QUADS];
     int item = first;
@@ -753,12 +775,16 @@ template <typename TOut>
 __global__ void __launch_bounds__(256)
 f1k_rows_inverse_kernel(const float2 *__restrict__ spec, const float *__restrict__ t, int th, int tw_,
                         const float *__restrict__ r, int H, int hp, const FftStats *__restrict__ stats,
-                        double min_std, double min_mean_diff, const float2 *__restrict__ twiddle,
+                        double min_std, double min_mean_diff, const float2 *__restrict__ twiddle_table,
                         TOut *__restrict__ out)
 {
     __shared__ float2 lds[4 * F1K_LDS];
+    __shared__ float2 twiddle[F1K];                 // LDS copy: gathered reads stay off the memory pipeline
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int y0 = 2 * (blockIdx.x * 4 + wave), pair = blockIdx.y;
+    for (int i = threadIdx.x; i < F1K; i += 256)
+        twiddle[i] = twiddle_table[i];
+    __syncthreads();
     if (y0 >= H)
         return;
     (void)t;
@@ -892,7 +918,11 @@ extern "C" int svamd_xcorr2d_fft(const float *tmpl, int th, int tw, const float 
         SV_LAUNCH_CHECK();
         const int tiles_per_pair = (ncols + F1K_TILE - 1) / F1K_TILE;
         const int total_tiles = tiles_per_pair * batch;
-        const int resident = 256;                 // one workgroup per CU (register-limited)
+#ifdef SV_F1K_GRID
+        const int resident = SV_F1K_GRID;
+#else
+        const int resident = 256 * (SV_F1K_MINWAVES * 4 / F1K_TILE);   // workgroups the chip holds at once
+#endif
         hipLaunchKernelGGL(f1k_cols_fused_kernel, dim3(total_tiles < resident ? total_tiles : resident),
                            dim3(64 * F1K_TILE), 0, st, spec_t, spec_r, ncols, hp, tiles_per_pair, total_tiles,
                            tw_h);
