@@ -21,6 +21,7 @@ import bench  # noqa: E402
 
 H = W = 4096
 WIN, MD = 31, int(os.environ.get('AB_MAX_DISP', 128))
+WIN_W = int(os.environ.get('AB_WIN_W', WIN))      # a width other than 7/11/15/21/31 takes the run-time-width kernel
 
 
 def load(path):
@@ -40,14 +41,14 @@ def main():
     libs = [load(p.split('@')[0]) for p in paths]
     left, right = bench.synthetic_pair(H, W, 1000)
     dl, dr = torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda()
-    nwy, nwx = H - WIN + 1, W - WIN + 1
+    nwy, nwx = H - WIN + 1, W - WIN_W + 1
     disp = torch.empty((nwy, nwx), dtype=torch.int32, device='cuda')
     val = torch.empty((nwy, nwx), dtype=torch.float64, device='cuda')
-    ws = torch.empty(libs[0].svamd_band_scan_u8_workspace_bytes(H, W, WIN, WIN), dtype=torch.uint8, device='cuda')
+    ws = torch.empty(libs[0].svamd_band_scan_u8_workspace_bytes(H, W, WIN_W, WIN), dtype=torch.uint8, device='cuda')
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     def run(lib, flags):
-        rc = lib.svamd_band_scan_u8(dl.data_ptr(), dr.data_ptr(), H, W, WIN, WIN, 1, 1, MD, 1, 0.5, 0.01,
+        rc = lib.svamd_band_scan_u8(dl.data_ptr(), dr.data_ptr(), H, W, WIN_W, WIN, 1, 1, MD, 1, 0.5, 0.01,
                                     0, nwy, flags, disp.data_ptr(), val.data_ptr(), None, ws.data_ptr(),
                                     ws.numel(), stream)
         assert rc == 0, lib.svamd_last_error()
@@ -72,7 +73,7 @@ def main():
             torch.cuda.synchronize()
             times[k].append(e0.elapsed_time(e1))
     for p, t in zip(paths, times):
-        print(f'{os.path.basename(p):<40} median {np.median(t):8.3f} ms  min {np.min(t):8.3f}  all {np.round(t, 2)}')
+        print(f'win {WIN_W}x{WIN} {os.path.basename(p):<40} median {np.median(t):8.3f} ms  min {np.min(t):8.3f}  all {np.round(t, 2)}')
 
 
 if __name__ == '__main__':

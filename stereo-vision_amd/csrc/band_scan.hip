@@ -22,6 +22,9 @@
 // loop is bound by the vector ALU, not by LDS.  Offsets are visited in ascending
 // order inside a lane, so the sequential selection rule needs no cross-lane
 // traffic at all; only the final results are written.
+#include <type_traits>
+#include <utility>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -239,6 +242,128 @@ __device__ __forceinline__ void accumulate(const float *__restrict__ lp, const f
     }
 }
 
+// acc.x += l.x * r; acc.y += l.y * r with r = half RH of rpair: the left operand
+// is taken as a pair (one value per window), the right one is broadcast.
+template <int RH>
+__device__ __forceinline__ void pk_fma_rbcast(float2v &acc, const float2v &lpair, const float2v &rpair)
+{
+    if constexpr (RH == 0)
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(lpair), "v"(rpair));
+    else
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(lpair), "v"(rpair));
+}
+
+// Element K (0 .. 11) of three consecutive quads, as the register pair that holds it.
+template <int K>
+__device__ __forceinline__ const float2v &pair_of3(const Quad &q0, const Quad &q1, const Quad &q2)
+{
+    const Quad &q = K < 4 ? q0 : (K < 8 ? q1 : q2);
+    return (K & 2) ? q.hi : q.lo;
+}
+
+template <int D, int DD = 0, typename F>
+__device__ __forceinline__ void for_each_offset(F &f)
+{
+    if constexpr (DD < D) {
+        f(std::integral_constant<int, DD>{});
+        for_each_offset<D, DD + 1>(f);
+    }
+}
+
+// Window width known only at run time: the four left columns ubase .. ubase + 3 of
+// one image row against the D offsets.  r0, r1, r2: right columns ubase .. ubase + 11.
+// INTERIOR: all four windows of the lane cover all four columns (both packed
+// multiplicands broadcast, as in the fixed-width kernels).  Otherwise the left
+// value is masked per window - window x covers columns x .. x + win_w - 1.
+template <int D, bool INTERIOR>
+__device__ __forceinline__ void quad_any(float2v (&acc)[BAND_X / 2][D], const Quad &lq, const Quad &r0,
+                                         const Quad &r1, const Quad &r2, int ubase, int win_w)
+{
+    auto column = [&](auto I_) {
+        constexpr int I = decltype(I_)::value;
+        const float2v &lp2 = (I & 2) ? lq.hi : lq.lo;
+        auto offsets = [&](auto fma) { for_each_offset<D>(fma); };
+        if constexpr (INTERIOR) {
+            offsets([&](auto DD_) {
+                constexpr int DD = decltype(DD_)::value, K = I + DD;
+                pk_fma_bcast<(I & 1), (K & 1)>(acc[0][DD], lp2, pair_of3<K>(r0, r1, r2));
+                pk_fma_bcast<(I & 1), (K & 1)>(acc[1][DD], lp2, pair_of3<K>(r0, r1, r2));
+            });
+        } else {
+            const int u = ubase + I;
+            if (u < win_w + BAND_X - 1) {                       // wave-uniform
+                const float l = (I & 1) ? lp2.y : lp2.x;
+                float2v lv[BAND_X / 2];
+#pragma unroll
+                for (int p = 0; p < BAND_X / 2; ++p) {
+                    lv[p].x = (u >= 2 * p && u < 2 * p + win_w) ? l : 0.f;
+                    lv[p].y = (u >= 2 * p + 1 && u < 2 * p + 1 + win_w) ? l : 0.f;
+                }
+                offsets([&](auto DD_) {
+                    constexpr int DD = decltype(DD_)::value, K = I + DD;
+                    pk_fma_rbcast<(K & 1)>(acc[0][DD], lv[0], pair_of3<K>(r0, r1, r2));
+                    pk_fma_rbcast<(K & 1)>(acc[1][DD], lv[1], pair_of3<K>(r0, r1, r2));
+                });
+            }
+        }
+    };
+    column(std::integral_constant<int, 0>{});
+    column(std::integral_constant<int, 1>{});
+    column(std::integral_constant<int, 2>{});
+    column(std::integral_constant<int, 3>{});
+}
+
+// accumulate() for a window width known only at run time (any width the tile
+// geometry admits): the same register tile, the row walked in groups of four
+// columns with the three right quads a group needs rotating through registers.
+template <int D, bool ALIGNED>
+__device__ __forceinline__ void accumulate_any(const float *__restrict__ lp, const float *__restrict__ rp,
+                                               int lpitch, int rpitch, int rows, int win_w,
+                                               float2v (&acc)[BAND_X / 2][D])
+{
+    static_assert(D <= 9, "three right quads cover offsets 0..8 only");
+    const int groups = (win_w + BAND_X - 1 + 3) / 4;
+    const int first_interior = 1, last_interior = (win_w - 4) / 4;   // groups c with 3 <= 4c and 4c + 3 <= win_w - 1
+    auto step = [&](int c, const Quad &r0, const Quad &r1, const Quad &r2) {
+        const Quad lq = load_quad<true>(lp + 4 * c);
+        if (c >= first_interior && c <= last_interior && win_w >= 4)
+            quad_any<D, true>(acc, lq, r0, r1, r2, 4 * c, win_w);
+        else
+            quad_any<D, false>(acc, lq, r0, r1, r2, 4 * c, win_w);
+    };
+#pragma unroll 1
+    for (int a = 0; a < rows; ++a) {
+        Quad r0 = load_quad<ALIGNED>(rp), r1 = load_quad<ALIGNED>(rp + 4), r2;
+        int c = 0;
+        for (;;) {
+            r2 = load_quad<ALIGNED>(rp + 4 * (c + 2));
+            step(c, r0, r1, r2);
+            if (++c >= groups) break;
+            r0 = load_quad<ALIGNED>(rp + 4 * (c + 2));
+            step(c, r1, r2, r0);
+            if (++c >= groups) break;
+            r1 = load_quad<ALIGNED>(rp + 4 * (c + 2));
+            step(c, r2, r0, r1);
+            if (++c >= groups) break;
+        }
+        lp += lpitch;
+        rp += rpitch;
+    }
+}
+
+// WIN_W > 0: the width is a compile-time constant (fully unrolled row); WIN_W == 0:
+// the width comes from the geometry at run time.
+template <int WIN_W, int D, bool ALIGNED>
+__device__ __forceinline__ void accumulate_rows(const float *__restrict__ lp, const float *__restrict__ rp,
+                                                int lpitch, int rpitch, int rows, int win_w,
+                                                float2v (&acc)[BAND_X / 2][D])
+{
+    if constexpr (WIN_W > 0)
+        accumulate<WIN_W, D, ALIGNED>(lp, rp, lpitch, rpitch, rows, acc);
+    else
+        accumulate_any<D, ALIGNED>(lp, rp, lpitch, rpitch, rows, win_w, acc);
+}
+
 struct LaneState {
     double s1l[BAND_X];    // sum of (L - 128) over the window
     double invl[BAND_X];   // 1 / sqrt(A_L)
@@ -390,8 +515,8 @@ band_scan_kernel(BandGeom g, const uint8_t *__restrict__ left, const uint8_t *__
         __syncthreads();
         if (active) {
             float2v acc[BAND_X / 2][1] = {};
-            accumulate<WIN_W, 1, true>(lp, Rt + lrow * g.lpitch + BAND_X * lane, g.lpitch, g.lpitch,
-                                       g.win_h, acc);
+            accumulate_rows<WIN_W, 1, true>(lp, Rt + lrow * g.lpitch + BAND_X * lane, g.lpitch, g.lpitch,
+                                            g.win_h, g.win_w, acc);
             finish_pass<1>(g, acc, g.max_disp, g.nd, true, wy, xbase, wsum_r, winv_r, st, nullptr);
         }
     }
@@ -407,14 +532,14 @@ band_scan_kernel(BandGeom g, const uint8_t *__restrict__ left, const uint8_t *__
         int k = k0;
         for (; k + BAND_D <= kend; k += BAND_D) {
             float2v acc[BAND_X / 2][BAND_D] = {};
-            accumulate<WIN_W, BAND_D, true>(lp, rp + (k - k0), g.lpitch, g.rpitch, g.win_h, acc);
+            accumulate_rows<WIN_W, BAND_D, true>(lp, rp + (k - k0), g.lpitch, g.rpitch, g.win_h, g.win_w, acc);
             finish_pass<BAND_D>(g, acc, k, kend, false, wy, xbase, wsum_r, winv_r, st, SV_SCORES_OUT);
             keep_pace(progress, wave, ++passes);
             SV_STAMP(1 + k / BAND_D);
         }
         for (; k < kend; ++k) {  // fewer than 8 offsets left in this chunk
             float2v acc[BAND_X / 2][1] = {};
-            accumulate<WIN_W, 1, false>(lp, rp + (k - k0), g.lpitch, g.rpitch, g.win_h, acc);
+            accumulate_rows<WIN_W, 1, false>(lp, rp + (k - k0), g.lpitch, g.rpitch, g.win_h, g.win_w, acc);
             finish_pass<1>(g, acc, k, kend, false, wy, xbase, wsum_r, winv_r, st, SV_SCORES_OUT);
         }
     }
@@ -566,14 +691,16 @@ extern "C" int svamd_band_scan_u8(const uint8_t *left, const uint8_t *right, int
     // Tile geometry.  Row pitches carry 4 floats of slack because the last
     // 4-wide LDS read of a lane may extend past the columns it uses.  As many
     // offsets as fit in LDS are staged per pass over the right image.
-    g.lpitch = (int)align_up((size_t)(BAND_TX + win_w - 1), 4) + 4;
+    const bool tuned = win_w == 7 || win_w == 11 || win_w == 15 || win_w == 21 || win_w == 31;
+    const int slack = tuned ? 4 : 12;   // the run-time-width row walk reads up to three quads ahead
+    g.lpitch = (int)align_up((size_t)(BAND_TX + win_w - 1), 4) + slack;
     size_t lds = 0;
     for (g.tile_wrows = BAND_WAVES; g.tile_wrows >= 1; --g.tile_wrows) {
         g.tile_rows = (g.tile_wrows - 1) * stride_y + win_h;
         g.dchunk = (int)align_up((size_t)g.nd, BAND_D);
         for (;;) {
             const int dcur = g.dchunk < g.nd ? g.dchunk : g.nd;
-            g.rpitch = (int)align_up((size_t)(BAND_TX + win_w - 1 + dcur - 1), 4) + 4;
+            g.rpitch = (int)align_up((size_t)(BAND_TX + win_w - 1 + dcur - 1), 4) + slack;
             if (g.rpitch < g.lpitch)
                 g.rpitch = g.lpitch;  // the centre pass stages a left-shaped tile into Rt
             lds = (size_t)g.tile_rows * (g.lpitch + g.rpitch) * sizeof(float);
@@ -608,9 +735,8 @@ extern "C" int svamd_band_scan_u8(const uint8_t *left, const uint8_t *right, int
         SV_BAND_CASE(15);
         SV_BAND_CASE(21);
         SV_BAND_CASE(31);
-    default:
-        SV_REQUIRE(false, SVAMD_ERR_LIMIT,
-                   "band_scan_u8: window width %d has no compiled kernel (available: 7, 11, 15, 21, 31)", win_w);
+    default:   // any other width: the kernel that takes it at run time
+        return band_launch<0>(g, lds, grid, st, left, right, wl, il, wr, ir, out_disp, out_val, scores);
     }
 #undef SV_BAND_CASE
 }

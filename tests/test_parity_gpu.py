@@ -420,8 +420,29 @@ def test_band_scan_rejects_unsupported(mods):
     b = mods['b']
     with pytest.raises(TypeError):
         b.band_scan(np.random.default_rng(0).random((40, 40)), np.zeros((40, 40)), 7, 7, 3)
-    with pytest.raises(mods['n'].NativeError, match='no compiled kernel'):
-        b.band_scan(np.zeros((40, 40), np.uint8), np.zeros((40, 40), np.uint8), 8, 8, 3)
+    with pytest.raises(mods['n'].NativeError, match='exceeds 1024'):
+        b.band_scan(np.zeros((80, 80), np.uint8), np.zeros((80, 80), np.uint8), 33, 32, 3)
+    with pytest.raises(mods['n'].NativeError, match='does not fit the LDS tile'):
+        b.band_scan(np.zeros((230, 280), np.uint8), np.zeros((230, 280), np.uint8), 5, 200, 6)
+
+
+@pytest.mark.parametrize('ww,wh,h,w,md,stride', [(8, 8, 40, 90, 10, 1), (12, 12, 50, 300, 17, 1), (25, 25, 60, 140, 9, 2),
+                                                 (40, 25, 47, 330, 12, 1), (3, 5, 20, 70, 4, 1), (1, 1, 9, 40, 3, 1),
+                                                 (2, 30, 64, 64, 8, 1), (5, 60, 90, 280, 6, 1), (64, 16, 40, 400, 130, 1)])
+def test_band_scan_any_window_width(mods, oracle, ww, wh, h, w, md, stride):
+    '''Window widths without a fixed-width kernel go through the run-time-width
+    kernel: same scores, disparities and selection as the oracle.'''
+    left, right = synthetic_pair(h, w, ww * 100 + wh, min(md, 12))
+    b = mods['b']
+    disp, val, scores = b.band_scan(left, right, ww, wh, md, row_stride=stride, want_scores=True)
+    odisp, oval, oscores = oracle.band_scan(left, right, ww, wh, md, stride_y=stride, want_scores=True)
+    assert_surface_close(scores, oscores, 1e-12, 'band scores')
+    assert np.array_equal(disp, odisp)
+    assert_surface_close(val, oval, 1e-12, 'band values')
+    disp, val = b.band_scan(left, right, ww, wh, md, correlation_threshold=0.4, row_stride=stride)
+    odisp, oval = oracle.band_scan(left, right, ww, wh, md, stride_y=stride, mode='fold', threshold=0.4)
+    assert np.array_equal(disp, odisp)
+    assert_surface_close(val, oval, 1e-12, 'band fold values')
 
 
 # ---- FFT route (power-of-two shapes) ------------------------------------------------
