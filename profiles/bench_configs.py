@@ -313,7 +313,30 @@ def config_peaks():
          seconds=time.perf_counter() - t0)
 
 
+def config_audio():
+    '''Long 1D circular correlation, the shape of the reference's audio search: a
+    5,000,000-sample recording as the template argument, a 200,000-sample snippet
+    as the signal.'''
+    rng = np.random.default_rng(5)
+    nt, ns, start = 5_000_000, 200_000, 3_141_592
+    recording = np.rint(3000 * rng.standard_normal(nt))
+    snippet = recording[start:start + ns] + 100 * rng.standard_normal(ns)
+    dt, out = timed(correlation_spectral.cross_correlate_1d_spectral, recording, snippet, repeat=2)
+    emit(config='N4', what='cross_correlate_1d_spectral, 5,000,000-sample template, 200,000-sample signal '
+         '(call incl. transfers)', seconds=dt, argmax=int(np.argmax(out)), expected_argmax=nt - 1 - start,
+         tflops=2.0 * ns * (nt + ns - 1) / dt / 1e12)
+    from scipy import fft as sfft
+    t0 = time.perf_counter()
+    n = nt + ns - 1
+    t = (recording - recording.mean()) / (recording.std() * nt)
+    padded = np.concatenate([np.zeros(nt - 1), snippet])
+    ref = np.real(sfft.ifft(np.conj(sfft.fft(t, n)) * sfft.fft(padded, n)))
+    emit(config='N4', what='cpu scipy.fft route of the same pair (1 thread)', seconds=time.perf_counter() - t0,
+         argmax=int(np.argmax(ref)), max_abs_difference=float(np.max(np.abs(ref - out))),
+         scale=float(np.max(np.abs(ref))))
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['1', '1d', '2', '3', '4b', '5', 'n1', 'n2']
+    which = sys.argv[1:] or ['1', '1d', '2', '3', '4b', '5', 'n1', 'n2', 'n4']
     for c in which:
-        {'1': config1, '1d': config1_device, '2': config2, 'n1': config_grids, 'n2': config_peaks, '3': config3, '4b': config4b, '5': config5}[c]()
+        {'1': config1, '1d': config1_device, '2': config2, 'n1': config_grids, 'n2': config_peaks, 'n4': config_audio, '3': config3, '4b': config4b, '5': config5}[c]()

@@ -239,6 +239,41 @@ extend_1d_circular_kernel(const double *__restrict__ sig, int64_t nt, int64_t ns
     }
 }
 
+// 1D circular, roles swapped (signal shorter than template): the mean-removed
+// template, zero-padded to N = ns + nt - 1 and wrapped: ext[i] = tN[i mod N].
+__global__ void __launch_bounds__(256)
+extend_1d_template_kernel(const double *__restrict__ t, int64_t nt, int64_t N, int64_t total,
+                          const Stats *__restrict__ st, float *__restrict__ ext)
+{
+    const double mean = st->mean;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t idx = i >= N ? i - N : i;
+        ext[i] = idx < nt ? (float)(t[idx] - mean) : 0.0f;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+to_float_kernel(const double *__restrict__ src, int64_t n, float *__restrict__ dst)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = (float)src[i];
+}
+
+// out[k] = raw[(nt - 1 - k) mod N] / (std * nt)
+__global__ void __launch_bounds__(256)
+scale_1d_swapped_kernel(const double *__restrict__ raw, int64_t N, int64_t nt, const Stats *__restrict__ s1,
+                        double *__restrict__ out)
+{
+    const int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (k >= N)
+        return;
+    int64_t u = nt - 1 - k;
+    if (u < 0)
+        u += N;
+    out[k] = raw[u] / (double)nt / s1->std;
+}
+
 // ---- the sliding dot product --------------------------------------------------------
 // Strided columns (sx > 1): one thread per output; a block covers 64 x 4 outputs.
 // Template values are wave-uniform and come in through the scalar data path.  Each
@@ -284,8 +319,9 @@ slide_kernel(const float *__restrict__ t, int th, int tw, const float *__restric
 // path.  The two halves of each accumulator pair are added at the end.
 //
 // A workgroup is up to 8 wavefronts = 8 consecutive output rows of the same
-// column tile and template-column chunk (at most 512 template columns; the
-// partial sums of several chunks are added by slide_reduce_kernel).  It walks down
+// column tile and slice of template-column chunks (512 template columns each; a
+// workgroup sums the chunks of its slice itself, slide_reduce_kernel adds the
+// slices).  It walks down
 // the image rows its outputs touch, staging up to 4 rows at a time in LDS
 // (double-buffered: the next rows are fetched into registers while the current
 // ones are used); image row r serves output row i as template row r - i * sy.
@@ -304,6 +340,7 @@ struct SlideGeom {
     int eh, ew;            // valid image rows / columns (anything beyond reads as 0)
     int64_t pitch;
     int waves, grows, rowlen;
+    int nchunks, chunks_per_slice;   // template-column chunks, and how many of them a workgroup sums itself
 };
 
 typedef float f2v __attribute__((ext_vector_type(2)));
@@ -364,9 +401,6 @@ slide_tiled_kernel(SlideGeom g, const float *__restrict__ tpk, const float *__re
     const int nthreads = g.waves * WAVE;
     const int c0 = blockIdx.x * ST_TILE;
     const int i0 = blockIdx.y * g.waves;
-    const int n0 = blockIdx.z * ST_CHUNK;
-    const int chunk = min(ST_CHUNK, g.lp - n0);
-    const int groups = chunk / 8;
     const int i = i0 + wave;
     const bool has_row = i < g.oh;
     const int r_first = i0 * g.sy;
@@ -374,6 +408,7 @@ slide_tiled_kernel(SlideGeom g, const float *__restrict__ tpk, const float *__re
     const int nsteps = (r_end - r_first + g.grows - 1) / g.grows;
     const int qpr = g.rowlen / 4, total_q = g.grows * qpr;
 
+    int n0 = 0;                      // first template column of the chunk in hand
     f4v stage[ST_STAGE_Q];
     auto fetch = [&](int step) {
 #pragma unroll
@@ -410,6 +445,12 @@ slide_tiled_kernel(SlideGeom g, const float *__restrict__ tpk, const float *__re
     double de[4] = {}, dodd[4] = {};
     int pending = 0;
 
+    const int ch_begin = blockIdx.z * g.chunks_per_slice;
+    const int ch_end = min(ch_begin + g.chunks_per_slice, g.nchunks);
+    for (int ch = ch_begin; ch < ch_end; ++ch) {
+    n0 = ch * ST_CHUNK;
+    const int chunk = min(ST_CHUNK, g.lp - n0);
+    const int groups = chunk / 8;
     fetch(0);
     store(0);
     __syncthreads();
@@ -454,6 +495,7 @@ slide_tiled_kernel(SlideGeom g, const float *__restrict__ tpk, const float *__re
             store((step + 1) & 1);
         __syncthreads();
     }
+    }
     if (!has_row)
         return;
     double *dst = out + ((int64_t)blockIdx.z * g.oh + i) * g.ow;
@@ -480,14 +522,16 @@ slide_reduce_kernel(const double *__restrict__ partial, int nz, int64_t total, d
 }
 
 static int slide_lp(int tw) { return (int)align_up((size_t)tw + 1, 8); }
-static int slide_nz(int tw) { return (slide_lp(tw) + ST_CHUNK - 1) / ST_CHUNK; }
+static int slide_chunks(int tw) { return (slide_lp(tw) + ST_CHUNK - 1) / ST_CHUNK; }
+constexpr int ST_MAX_SLICES = 16;   // partial-sum planes at most (workgroups sum the chunks of a slice themselves)
 
 size_t slide_pack_floats(int th, int tw) { return (size_t)th * 2 * slide_lp(tw); }
 
 size_t slide_partial_doubles(int tw, int64_t oh, int64_t ow)
 {
-    const int nz = slide_nz(tw);
-    return nz > 1 ? (size_t)nz * (size_t)oh * (size_t)ow : 0;
+    const int nchunks = slide_chunks(tw);
+    const int planes = nchunks < ST_MAX_SLICES ? nchunks : ST_MAX_SLICES;
+    return planes > 1 ? (size_t)planes * (size_t)oh * (size_t)ow : 0;
 }
 
 int slide_launch(const float *t, int th, int tw, const float *img, int64_t img_pitch, int eh, int ew,
@@ -504,7 +548,7 @@ int slide_launch(const float *t, int th, int tw, const float *img, int64_t img_p
     SlideGeom g;
     g.th = th; g.tw = tw; g.lp = slide_lp(tw);
     g.oh = oh; g.ow = ow; g.sy = sy; g.eh = eh; g.ew = ew; g.pitch = img_pitch;
-    const int nz = slide_nz(tw);
+    g.nchunks = slide_chunks(tw);
     g.waves = oh < ST_WAVES ? oh : ST_WAVES;
     g.rowlen = ST_TILE + (g.lp < ST_CHUNK ? g.lp : ST_CHUNK) + 8;
     const int qpr = g.rowlen / 4;
@@ -518,7 +562,16 @@ int slide_launch(const float *t, int th, int tw, const float *img, int64_t img_p
     hipLaunchKernelGGL(pack_template_kernel, dim3(grid_for((int64_t)th * 2 * g.lp)), dim3(256), 0, stream, t,
                        th, tw, g.lp, pack);
     SV_LAUNCH_CHECK();
-    dim3 grid((ow + ST_TILE - 1) / ST_TILE, (unsigned)gy, nz);
+    // Template chunks are spread over up to ST_MAX_SLICES grid slices when the output
+    // alone does not give the chip enough workgroups; a slice sums its chunks itself.
+    const int64_t gx = ((int64_t)ow + ST_TILE - 1) / ST_TILE;
+    int64_t want = (2048 + gx * gy - 1) / (gx * gy);
+    if (want > ST_MAX_SLICES) want = ST_MAX_SLICES;
+    if (want > g.nchunks) want = g.nchunks;
+    if (want < 1) want = 1;
+    g.chunks_per_slice = (int)((g.nchunks + want - 1) / want);
+    const int nz = (g.nchunks + g.chunks_per_slice - 1) / g.chunks_per_slice;
+    dim3 grid((unsigned)gx, (unsigned)gy, nz);
     const size_t lds = (size_t)2 * g.grows * g.rowlen * sizeof(float);
     hipLaunchKernelGGL(slide_tiled_kernel, grid, dim3(g.waves * WAVE), lds, stream, g, pack, img,
                        nz > 1 ? partial : out);
@@ -823,13 +876,22 @@ extern "C" int svamd_cross_correlate_1d(const double *v1, const double *v2, int6
 }
 
 // ================================ a5 ==========================================
+// The circular correlation sums nt * N products when the template slides over the
+// padded signal and ns * N when the signal slides over the padded template: the
+// shorter array slides.
 extern "C" size_t svamd_cross_correlate_1d_spectral_workspace_bytes(int64_t nt, int64_t ns)
 {
     if (nt <= 0 || ns <= 0)
         return 0;
-    return 256 + align_up(stats_scratch_doubles() * 8, 256) + align_up((size_t)nt * 4, 256) + align_up((size_t)(ns + 2 * nt - 2) * 4, 256) +
+    const int64_t N = ns + nt - 1;
+    const size_t common = 256 + align_up(stats_scratch_doubles() * 8, 256);
+    if (ns < nt)
+        return common + align_up((size_t)ns * 4, 256) + align_up((size_t)(N + ns - 1) * 4, 256) +
+               align_up((size_t)N * 8, 256) + align_up(slide_pack_floats(1, (int)ns) * 4, 256) +
+               align_up(slide_partial_doubles((int)ns, 1, N) * 8, 256);
+    return common + align_up((size_t)nt * 4, 256) + align_up((size_t)(ns + 2 * nt - 2) * 4, 256) +
            align_up(slide_pack_floats(1, (int)nt) * 4, 256) +
-           align_up(slide_partial_doubles((int)nt, 1, ns + nt - 1) * 8, 256);
+           align_up(slide_partial_doubles((int)nt, 1, N) * 8, 256);
 }
 
 extern "C" int svamd_cross_correlate_1d_spectral(const double *tmpl, int64_t nt, const double *signal,
@@ -847,13 +909,34 @@ extern "C" int svamd_cross_correlate_1d_spectral(const double *tmpl, int64_t nt,
     Carver ws(workspace);
     Stats *s1 = ws.take<Stats>(1);
     double *sscr = ws.take<double>(stats_scratch_doubles());
-    float *tp = ws.take<float>((size_t)nt);
-    float *ext = ws.take<float>((size_t)(ns + 2 * nt - 2));
-    float *pack = ws.take<float>(slide_pack_floats(1, (int)nt));
-    double *partial = ws.take<double>(slide_partial_doubles((int)nt, 1, ns + nt - 1));
     const int64_t N = ns + nt - 1;
     int rc;
     if ((rc = stats_launch(tmpl, SVAMD_F64, 1, (int)nt, nt, false, s1, sscr, st)) != SVAMD_OK) return rc;
+    if (ns < nt) {
+        // c[k] = sum_j signal[j] * tN[(nt - 1 + j - k) mod N]: the raw signal slides over the
+        // wrapped, zero-padded template; output position u = (nt - 1 - k) mod N
+        float *sp = ws.take<float>((size_t)ns);
+        float *ext = ws.take<float>((size_t)(N + ns - 1));
+        double *raw = ws.take<double>((size_t)N);
+        float *pack = ws.take<float>(slide_pack_floats(1, (int)ns));
+        double *partial = ws.take<double>(slide_partial_doubles((int)ns, 1, N));
+        hipLaunchKernelGGL(to_float_kernel, dim3(grid_for(ns)), dim3(256), 0, st, signal, ns, sp);
+        SV_LAUNCH_CHECK();
+        hipLaunchKernelGGL(extend_1d_template_kernel, dim3(grid_for(N + ns - 1)), dim3(256), 0, st, tmpl, nt, N,
+                           N + ns - 1, s1, ext);
+        SV_LAUNCH_CHECK();
+        if ((rc = slide_launch(sp, 1, (int)ns, ext, N + ns - 1, 1, (int)(N + ns - 1), 1, (int)N, 1, 1, raw, pack,
+                               partial, st)) != SVAMD_OK)
+            return rc;
+        hipLaunchKernelGGL(scale_1d_swapped_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, raw, N,
+                           nt, s1, out);
+        SV_LAUNCH_CHECK();
+        return SVAMD_OK;
+    }
+    float *tp = ws.take<float>((size_t)nt);
+    float *ext = ws.take<float>((size_t)(ns + 2 * nt - 2));
+    float *pack = ws.take<float>(slide_pack_floats(1, (int)nt));
+    double *partial = ws.take<double>(slide_partial_doubles((int)nt, 1, N));
     hipLaunchKernelGGL(prep_template_kernel, dim3(grid_for(nt)), dim3(256), 0, st, tmpl, SVAMD_F64, 1,
                        (int)nt, nt, 1, (int)nt, s1, tp);
     SV_LAUNCH_CHECK();

@@ -184,6 +184,21 @@ def test_1d_lengths_vs_oracle(mods, oracle, n):
                  f'spectral n={n}')
         close_1d(mods['s'].cross_correlate_1d_spectral(v1[:n // 2 + 1], v2),
                  oracle.cross_correlate_1d_spectral(v1[:n // 2 + 1], v2), f'spectral uneven n={n}')
+        # a signal shorter than the template: the kernel lets the signal slide instead
+        close_1d(mods['s'].cross_correlate_1d_spectral(v1, v2[:n // 2]),
+                 oracle.cross_correlate_1d_spectral(v1, v2[:n // 2]), f'spectral short signal n={n}')
+
+
+def test_1d_spectral_long_template_short_signal(mods, oracle):
+    '''The audio-search shape of the reference's music demo: a long recording as
+    the template argument, a short snippet as the signal.'''
+    rng = np.random.default_rng(99)
+    long = rng.standard_normal(30000) * 1000
+    snippet = long[12345:12345 + 2100] + 50 * rng.standard_normal(2100)
+    got = mods['s'].cross_correlate_1d_spectral(long, snippet)
+    want = oracle.cross_correlate_1d_spectral(long, snippet)
+    close_1d(got, want, 'long template')
+    assert int(np.argmax(got)) == int(np.argmax(want))
 
 
 def test_1d_unequal_raises(mods):
@@ -632,6 +647,18 @@ def test_driver_signal_offset(mods, monkeypatch, capsys):
     for out in (spatial, spectral):
         assert 'Max at: 44136' in out
         assert 'Number of signals shifted: 136' in out
+
+
+def test_driver_music_patterns(mods, monkeypatch, capsys):
+    '''Every snippet of the synthetic recording is found where it was cut out:
+    with template = recording (nt samples) and signal = snippet starting at s,
+    the circular correlation peaks at lag nt - 1 - s.'''
+    import music_patterns_africa as drv
+    out = run_driver('music_patterns_africa', ['--synthetic', '--no_plot'], monkeypatch, capsys)
+    signal, _, starts = drv.synthetic_recording()
+    for name, _, label in drv.SNIPPETS:
+        assert f'{label} correlation complete' in out
+        assert f'{label} maximum at: {len(signal) - 1 - starts[name]}' in out
 
 
 def test_driver_image_comparison(mods, tmp_path, monkeypatch, capsys):
