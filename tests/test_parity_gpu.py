@@ -649,6 +649,35 @@ def test_driver_signal_offset(mods, monkeypatch, capsys):
         assert 'Number of signals shifted: 136' in out
 
 
+def test_driver_1d_xcorr_and_numba_twins(mods, oracle, monkeypatch, capsys):
+    import correlation
+    import correlation_numba
+    import test_1d_xcorr as drv
+    monkeypatch.setattr(correlation, 'PRINT_PROGRESS', False)
+    monkeypatch.setattr('sys.argv', ['test_1d_xcorr', '--no_plot'])
+    results = dict(drv.main())
+    out = capsys.readouterr().out
+    for label in ('raw custom correlation', 'vectorised custom correlation', 'spectral correlation',
+                  'Numpy correlation'):
+        assert f'Time elapsed ({label})' in out
+    # the normalised numpy correlation differs from the un-normalised custom one only by a factor
+    x = np.arange(0, 4 * np.pi + drv.STEP_SIZE, drv.STEP_SIZE)
+    want = oracle.cross_correlate_1d(np.cos(x), -np.sin(x))
+    close_1d(results['vectorised custom correlation'], want, 'driver xc')
+    close_1d(np.array(results['raw custom correlation']), want, 'driver raw')
+    # the "Numba" twins: same values; unequal lengths print and return None
+    v = np.random.default_rng(1).standard_normal(300)
+    close_1d(correlation_numba.cross_correlate_1d_numba(v, v[::-1].copy()),
+             oracle.cross_correlate_1d(v, v[::-1].copy()), 'numba twin')
+    assert isinstance(correlation_numba.cross_correlate_1d_raw_numba(list(v), list(v)), list)
+    assert correlation_numba.cross_correlate_1d_numba(v, v[:10]) is None
+    assert 'Error: Vectors are of unequal length.' in capsys.readouterr().out
+    import numba_tests
+    numba_tests.main()
+    out = capsys.readouterr().out
+    assert 'Raw python, with Numba JIT; time elapsed' in out and 'Vectorisation, with Numba JIT; time elapsed' in out
+
+
 def test_driver_music_patterns(mods, monkeypatch, capsys):
     '''Every snippet of the synthetic recording is found where it was cut out:
     with template = recording (nt samples) and signal = snippet starting at s,
