@@ -116,10 +116,23 @@ def test_g5_1d(oracle):
     close(fs[::16], g['cs_spec_dec'], 1e-9)
 
 
-def check_scan(oracle, g, left, right):
+_CONE_SCANS = {}
+
+
+def cone_scan(oracle, seq_cfg):
+    '''The oracle's scan of the cone pair for one sequence config, computed once
+    per test session (several tests look at the same scans).'''
+    key = json.dumps(seq_cfg, sort_keys=True)
+    if key not in _CONE_SCANS:
+        im = golden('g6_cone_images')
+        _CONE_SCANS[key] = oracle.sequence_scan(im['left'] / 255.0, im['right'] / 255.0, seq_cfg)
+    return _CONE_SCANS[key]
+
+
+def check_scan(oracle, g, left=None, right=None):
     cfg = json.loads(str(g['config']))
     for s in range(int(g['n_seq'])):
-        res = oracle.sequence_scan(left, right, cfg[s])
+        res = cone_scan(oracle, cfg[s]) if left is None else oracle.sequence_scan(left, right, cfg[s])
         for st, windows in enumerate(res):
             want = g[f'seq{s}_stage{st}_windows']
             assert len(windows) == len(want)
@@ -141,8 +154,7 @@ def check_scan(oracle, g, left, right):
 
 @pytest.mark.parametrize('cfg', ['scan_config_portal', 'scan_config', 'scan_config_test_2'])
 def test_g6_cone_scans(oracle, cfg):
-    im = golden('g6_cone_images')
-    check_scan(oracle, golden(f'g6_cone_{cfg}'), im['left'] / 255.0, im['right'] / 255.0)
+    check_scan(oracle, golden(f'g6_cone_{cfg}'))
 
 
 def test_g6_box_test1(oracle):
@@ -151,8 +163,7 @@ def test_g6_box_test1(oracle):
 
 
 def test_g9_multipass(oracle):
-    im = golden('g6_cone_images')
-    check_scan(oracle, golden('g9_cone_multipass'), im['left'] / 255.0, im['right'] / 255.0)
+    check_scan(oracle, golden('g9_cone_multipass'))
 
 
 def test_g8_dense_u8(oracle):
@@ -166,11 +177,9 @@ def test_g10_depth_grids(oracle, tag):
     '''The grids the reference's stereo driver saves (sum over sequences, average
     by contributions) from the oracle's scan results: identical, bit for bit.'''
     g = golden('g10_cone_depth_grids')
-    im = golden('g6_cone_images')
-    left, right = im['left'] / 255.0, im['right'] / 255.0
     cfg = json.loads(str(g[f'{tag}_config']))
-    results = [oracle.sequence_scan(left, right, seq) for seq in cfg]
-    grids = oracle.depth_grids(results, left.shape)
+    results = [cone_scan(oracle, seq) for seq in cfg]
+    grids = oracle.depth_grids(results, golden('g6_cone_images')['left'].shape)
     for got, key in zip(grids, ('depth_grid', 'dp_x_grid', 'dp_y_grid', 'contributions_grid')):
         assert np.array_equal(got, g[f'{tag}_{key}']), key
 
