@@ -2,14 +2,15 @@
 // pairs at once, the globally normalised circular cross-correlation surface of
 // the pair and its maximum, followed by the per-window selection rule.
 //
-// One 256-thread workgroup per pair.  The workgroup reduces the float64 sums of
-// both boxes (two passes: mean, then squared deviations), stages the
-// mean-removed template and a horizontally wrapped copy of the mean-removed
-// region in LDS, and evaluates the surface directly,
+// Per pair: the float64 sums of both boxes (two passes: mean, then squared
+// deviations), the mean-removed template and a wrapped copy of the mean-removed
+// region staged in LDS, and the surface evaluated directly,
 //     c[k][l] = sum_{m<mh, n<mw} t'[m][n] * r'[(m + k) mod rh][(n + l) mod rw],
-// which is what conj(FFT(t')) * FFT(r') transforms back to.  The multiply-
-// accumulate runs in float32 (rows summed in float32, rows added in float64) or
-// entirely in float64; statistics, scaling and the max-reduction are float64.
+// which is what conj(FFT(t')) * FFT(r') transforms back to.  Statistics, scaling
+// and the max-reduction are float64.  The multiply-accumulate runs either in
+// float64 (scan_pairs_kernel: one workgroup per pair, four surface elements per
+// thread) or in float32 with packed FMAs (scan_pairs_f32_kernel: one wavefront
+// per group of pairs, short float32 runs folded into float64).
 #include "common.h"
 #include "kernels.h"
 
@@ -231,6 +232,316 @@ scan_pairs_kernel(const double *__restrict__ tbase, const double *__restrict__ r
     }
 }
 
+// ---- float32 multiply-accumulate: one wavefront per group of pairs ---------------------
+// The same surface with packed FMAs.  A lane owns a task = two vertically adjacent
+// surface rows (k, k + 1) x G adjacent columns; its G accumulators are register
+// pairs (row k, row k + 1).  The region is staged as rows of such pairs,
+//     S[a][x] = (r'[a][x mod rw], r'[(a + 1) mod rh][x mod rw]),
+// so one 16-byte LDS read delivers two columns of both rows and every template
+// value t'[m][n] (read four at a time, the same address for the whole pair) is
+// issued as one v_pk_fma_f32 per column with t' broadcast to both halves: 4 G
+// packed FMAs per three (G = 8) or two (G = 4) 16-byte window reads.  The window
+// of G + 4 columns rotates through registers.  Partial sums stay in float32 for
+// about 256 products and are then folded into float64.
+// Small pairs leave most of a wavefront's lanes without a task, so a wavefront
+// takes P = 64 / tasks pairs at a time (each with its own LDS slot).
+typedef float pf2 __attribute__((ext_vector_type(2)));
+typedef float pf4 __attribute__((ext_vector_type(4)));
+
+template <int TH>
+__device__ __forceinline__ void pk_fma_tb(pf2 &acc, const pf2 &tpair, const pf2 &w)
+{
+    if constexpr (TH == 0)
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(tpair), "v"(w));
+    else
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(tpair), "v"(w));
+}
+
+struct ColQuad {           // four consecutive columns of a row pair
+    pf2 c[4];
+};
+
+__device__ __forceinline__ ColQuad load_colquad(const float *p)
+{
+    const pf4 lo = *reinterpret_cast<const pf4 *>(p), hi = *reinterpret_cast<const pf4 *>(p + 4);
+    ColQuad q;
+    q.c[0] = lo.xy;
+    q.c[1] = lo.zw;
+    q.c[2] = hi.xy;
+    q.c[3] = hi.zw;
+    return q;
+}
+
+template <int G, int I = 0, int J = 0>
+__device__ __forceinline__ void pair_group(pf2 (&acc)[G], const pf4 &t, const ColQuad &q0, const ColQuad &q1,
+                                           const ColQuad &q2)
+{
+    if constexpr (I < 4) {
+        if constexpr (J < G) {
+            constexpr int C = I + J;
+            const ColQuad &q = C < 4 ? q0 : (C < 8 ? q1 : q2);
+            const pf2 tp = (I & 2) ? pf2(t.zw) : pf2(t.xy);
+            pk_fma_tb<(I & 1)>(acc[J], tp, q.c[C & 3]);
+            pair_group<G, I, J + 1>(acc, t, q0, q1, q2);
+        } else {
+            pair_group<G, I + 1, 0>(acc, t, q0, q1, q2);
+        }
+    }
+}
+
+// One template row (groups * 4 columns, zero padded) against one row pair of S,
+// starting at the task's first column.
+template <int G>
+__device__ __forceinline__ void pair_row(pf2 (&acc)[G], const float *__restrict__ trow,
+                                         const float *__restrict__ srow, int groups)
+{
+    ColQuad q0 = load_colquad(srow), q1, q2;
+    int g = 0;
+    if constexpr (G == 8) {
+        q1 = load_colquad(srow + 8);
+        for (;;) {
+            q2 = load_colquad(srow + 8 * (g + 2));
+            pair_group<G>(acc, *reinterpret_cast<const pf4 *>(trow + 4 * g), q0, q1, q2);
+            if (++g >= groups) break;
+            q0 = load_colquad(srow + 8 * (g + 2));
+            pair_group<G>(acc, *reinterpret_cast<const pf4 *>(trow + 4 * g), q1, q2, q0);
+            if (++g >= groups) break;
+            q1 = load_colquad(srow + 8 * (g + 2));
+            pair_group<G>(acc, *reinterpret_cast<const pf4 *>(trow + 4 * g), q2, q0, q1);
+            if (++g >= groups) break;
+        }
+    } else {
+        for (;;) {
+            q1 = load_colquad(srow + 8 * (g + 1));
+            pair_group<G>(acc, *reinterpret_cast<const pf4 *>(trow + 4 * g), q0, q1, q1);
+            if (++g >= groups) break;
+            q0 = load_colquad(srow + 8 * (g + 1));
+            pair_group<G>(acc, *reinterpret_cast<const pf4 *>(trow + 4 * g), q1, q0, q0);
+            if (++g >= groups) break;
+        }
+    }
+}
+
+struct SlotInfo {
+    double tmean, rmean, tstd, rstd;
+    int th, tw, rh, rw;
+    int state;        // 0: evaluate; 1: constant surface (low-deviation template); 2: invalid -> NaN; 3: no pair
+    int pad;
+};
+
+constexpr int PAIR_MAX_SLOTS = 16;
+constexpr int PAIR_FLUSH = 256;     // float32 products per accumulator between float64 folds
+
+__device__ __forceinline__ BestNan wave_best(BestNan v)
+{
+#pragma unroll
+    for (int o = WAVE / 2; o > 0; o >>= 1) {
+        BestNan n;
+        n.best = __shfl_xor(v.best, o, WAVE);
+        n.arg = __shfl_xor(v.arg, o, WAVE);
+        n.has_nan = __shfl_xor(v.has_nan, o, WAVE);
+        v = combine(v, n);
+    }
+    return v;
+}
+
+template <int G>
+__global__ void __launch_bounds__(WAVE)
+scan_pairs_f32_kernel(const double *__restrict__ tbase, const double *__restrict__ rbase,
+                      const PairDesc *__restrict__ desc, int64_t npairs, int max_side, int slots,
+                      int tasks_per_slot, int slot_floats, int t_floats, double min_std,
+                      double min_mean_diff, double *__restrict__ out_max, int64_t *__restrict__ out_argmax,
+                      double *__restrict__ surfaces, const int64_t *__restrict__ surf_off)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    __shared__ SlotInfo info[PAIR_MAX_SLOTS];
+    float *lds = reinterpret_cast<float *>(smem_raw);
+    const int lane = threadIdx.x;
+
+    for (int64_t base = (int64_t)blockIdx.x * slots; base < npairs; base += (int64_t)gridDim.x * slots) {
+        __syncthreads();   // LDS reuse across iterations
+        // ---- statistics and staging, one slot after the other, all lanes ----
+        for (int s = 0; s < slots; ++s) {
+            const int64_t p = base + s;
+            if (p >= npairs) {
+                if (lane == 0)
+                    info[s].state = 3;
+                continue;
+            }
+            const PairDesc d = desc[p];
+            const int th = (int)d.t_h, tw = (int)d.t_w, rh = (int)d.r_h, rw = (int)d.r_w;
+            if (rh <= 0 || rw <= 0 || th < 0 || tw < 0 || th > max_side || tw > max_side || rh > max_side ||
+                rw > max_side) {
+                if (lane == 0)
+                    info[s].state = 2;
+                continue;
+            }
+            const double *T = tbase + d.t_off;
+            const double *R = rbase + d.r_off;
+            const int tn = th * tw, rn = rh * rw;
+            double ts = 0.0, rs = 0.0;
+            for (int i = lane; i < tn; i += WAVE) {
+                const int y = i / tw, x = i - y * tw;
+                ts += T[y * d.t_pitch + x];
+            }
+            for (int i = lane; i < rn; i += WAVE) {
+                const int y = i / rw, x = i - y * rw;
+                rs += R[y * d.r_pitch + x];
+            }
+            const double tmean = wave_sum(ts) / (double)tn, rmean = wave_sum(rs) / (double)rn;
+            double tq = 0.0, rq = 0.0;
+            for (int i = lane; i < tn; i += WAVE) {
+                const int y = i / tw, x = i - y * tw;
+                const double v = T[y * d.t_pitch + x] - tmean;
+                tq += v * v;
+            }
+            for (int i = lane; i < rn; i += WAVE) {
+                const int y = i / rw, x = i - y * rw;
+                const double v = R[y * d.r_pitch + x] - rmean;
+                rq += v * v;
+            }
+            const double tstd = sqrt(wave_sum(tq) / (double)tn), rstd = sqrt(wave_sum(rq) / (double)rn);
+            const bool flat = tstd < min_std;
+            if (lane == 0) {
+                info[s].tmean = tmean;
+                info[s].rmean = rmean;
+                info[s].tstd = tstd;
+                info[s].rstd = rstd;
+                info[s].th = th;
+                info[s].tw = tw;
+                info[s].rh = rh;
+                info[s].rw = rw;
+                info[s].state = flat ? 1 : 0;
+            }
+            if (flat)
+                continue;
+            const int mh = min(th, rh), mw = min(tw, rw);
+            const int mwp = (mw + 3) & ~3;
+            const int gcols = (rw + G - 1) / G * G;
+            const int rxp = (gcols + mwp + 8 + 3) & ~3;
+            float *Ts = lds + (size_t)s * slot_floats, *Ss = Ts + t_floats;
+            for (int i = lane; i < mh * mwp; i += WAVE) {
+                const int y = i / mwp, x = i - y * mwp;
+                Ts[i] = x < mw ? (float)(T[y * d.t_pitch + x] - tmean) : 0.0f;
+            }
+            for (int i = lane; i < rh * rxp; i += WAVE) {
+                const int a = i / rxp, x = i - a * rxp;
+                const int xs = x % rw, a1 = a + 1 < rh ? a + 1 : 0;
+                Ss[2 * i] = (float)(R[a * d.r_pitch + xs] - rmean);
+                Ss[2 * i + 1] = (float)(R[a1 * d.r_pitch + xs] - rmean);
+            }
+        }
+        __syncthreads();
+
+        // ---- the surfaces: lane -> (slot, task) ----
+        const int slot = slots > 1 ? lane / tasks_per_slot : 0;
+        const int first_task = slots > 1 ? lane - slot * tasks_per_slot : lane;
+        const int task_step = slots > 1 ? 0x40000000 : WAVE;
+        BestNan mine;
+        mine.best = -INFINITY;
+        mine.arg = 0x7fffffff;
+        mine.has_nan = 0;
+        if (slot < slots && info[slot].state == 0) {
+            const SlotInfo si = info[slot];
+            const int64_t p = base + slot;
+            const int mh = min(si.th, si.rh), mw = min(si.tw, si.rw);
+            const int mwp = (mw + 3) & ~3;
+            const int lgroups = (si.rw + G - 1) / G;
+            const int rxp = (lgroups * G + mwp + 8 + 3) & ~3;
+            const int ntasks = (si.rh + 1) / 2 * lgroups;
+            const int tn = si.th * si.tw;
+            const float *Ts = lds + (size_t)slot * slot_floats, *Ss = Ts + t_floats;
+            const double scale = tn == 0 ? ((si.rstd > 0.0) ? 0.0 : NAN) : 1.0 / (si.tstd * (double)tn) / si.rstd;
+            double *surf = surfaces ? surfaces + surf_off[p] : nullptr;
+            const int flush_rows = mwp >= PAIR_FLUSH ? 1 : PAIR_FLUSH / (mwp > 0 ? mwp : 1);
+            for (int task = first_task; task < ntasks; task += task_step) {
+                const int kp = task / lgroups, l0 = (task - kp * lgroups) * G, k = 2 * kp;
+                pf2 acc[G];
+                double d0[G], d1[G];
+#pragma unroll
+                for (int j = 0; j < G; ++j) {
+                    acc[j] = pf2{0.f, 0.f};
+                    d0[j] = d1[j] = 0.0;
+                }
+                int since = 0;
+                for (int m = 0; m < mh; ++m) {
+                    int a = k + m;
+                    if (a >= si.rh)
+                        a -= si.rh;
+                    if (mwp > 0)
+                        pair_row<G>(acc, Ts + m * mwp, Ss + 2 * (a * rxp + l0), mwp / 4);
+                    if (++since == flush_rows || m == mh - 1) {
+                        since = 0;
+#pragma unroll
+                        for (int j = 0; j < G; ++j) {
+                            d0[j] += (double)acc[j].x;
+                            d1[j] += (double)acc[j].y;
+                            acc[j] = pf2{0.f, 0.f};
+                        }
+                    }
+                }
+#pragma unroll
+                for (int row = 0; row < 2; ++row) {
+                    if (k + row >= si.rh)
+                        continue;
+#pragma unroll
+                    for (int j = 0; j < G; ++j) {
+                        if (l0 + j >= si.rw)
+                            continue;
+                        const int idx = (k + row) * si.rw + l0 + j;
+                        const double v = tn == 0 ? scale : (row ? d1[j] : d0[j]) * scale;
+                        if (surf)
+                            surf[idx] = v;
+                        if (isnan(v)) {
+                            mine.has_nan = 1;
+                        } else if (v > mine.best || (v == mine.best && idx < mine.arg)) {
+                            mine.best = v;
+                            mine.arg = idx;
+                        }
+                    }
+                }
+            }
+        }
+        // ---- per-slot results ----
+        for (int s = 0; s < slots; ++s) {
+            const int state = info[s].state;
+            if (state == 3)
+                continue;
+            const int64_t p = base + s;
+            if (state == 0) {
+                BestNan v = mine;
+                if (slot != s) {
+                    v.best = -INFINITY;
+                    v.arg = 0x7fffffff;
+                    v.has_nan = 0;
+                }
+                v = wave_best(v);
+                if (lane == 0) {
+                    out_max[p] = v.has_nan ? NAN : v.best;
+                    if (out_argmax)
+                        out_argmax[p] = v.arg == 0x7fffffff ? -1 : v.arg;
+                }
+            } else if (state == 1) {
+                const double fill = fabs(info[s].tmean - info[s].rmean) < min_mean_diff ? 1.0 : 0.0;
+                if (surfaces) {
+                    double *surf = surfaces + surf_off[p];
+                    for (int i = lane; i < info[s].rh * info[s].rw; i += WAVE)
+                        surf[i] = fill;
+                }
+                if (lane == 0) {
+                    out_max[p] = fill;
+                    if (out_argmax)
+                        out_argmax[p] = 0;
+                }
+            } else if (lane == 0) {
+                out_max[p] = NAN;
+                if (out_argmax)
+                    out_argmax[p] = -1;
+            }
+        }
+    }
+}
+
 // image_scan's sequential selection rule, one thread per window.
 __global__ void __launch_bounds__(256)
 scan_fold_kernel(const double *__restrict__ corr_max, const uint8_t *__restrict__ is_centre,
@@ -291,10 +602,40 @@ extern "C" int svamd_scan_pairs(const double *tbase, const double *rbase, const 
     const unsigned grid = (unsigned)(npairs < (1 << 20) ? npairs : (1 << 20));
     const PairDesc *pd = reinterpret_cast<const PairDesc *>(desc);
     if (acc_precision == SVAMD_ACC_F32) {
-        const size_t lds = elems * sizeof(float);
-        hipLaunchKernelGGL((scan_pairs_kernel<float>), dim3(grid), dim3(threads), lds, st, tbase, rbase, pd,
-                           npairs, max_side, min_std, min_mean_diff, out_max, out_argmax, surfaces,
-                           surf_off);
+        // columns per task: 8 unless 4 wastes fewer padded columns
+        const int cols4 = (max_side + 3) / 4 * 4, cols8 = (max_side + 7) / 8 * 8;
+        const int G = cols8 == cols4 ? 8 : 4;
+        const int gcols = G == 8 ? cols8 : cols4;
+        const int t_floats = max_side * (int)side4;
+        const int rxp = (gcols + (int)side4 + 8 + 3) & ~3;
+        const int slot_floats = t_floats + 2 * max_side * rxp;
+        const int tasks_per_slot = (max_side + 1) / 2 * (gcols / G);
+        int slots = WAVE / tasks_per_slot;
+        if (slots < 1) slots = 1;
+        if (slots > PAIR_MAX_SLOTS) slots = PAIR_MAX_SLOTS;
+        const size_t lds = (size_t)slots * slot_floats * sizeof(float);
+        const int64_t groups = (npairs + slots - 1) / slots;
+        const unsigned fgrid = (unsigned)(groups < (1 << 20) ? groups : (1 << 20));
+        static bool raised4 = false, raised8 = false;
+        if (G == 8) {
+            if (lds > 64 * 1024 && !raised8) {
+                SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_pairs_f32_kernel<8>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+                raised8 = true;
+            }
+            hipLaunchKernelGGL((scan_pairs_f32_kernel<8>), dim3(fgrid), dim3(WAVE), lds, st, tbase, rbase, pd, npairs,
+                               max_side, slots, tasks_per_slot, slot_floats, t_floats, min_std, min_mean_diff,
+                               out_max, out_argmax, surfaces, surf_off);
+        } else {
+            if (lds > 64 * 1024 && !raised4) {
+                SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_pairs_f32_kernel<4>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+                raised4 = true;
+            }
+            hipLaunchKernelGGL((scan_pairs_f32_kernel<4>), dim3(fgrid), dim3(WAVE), lds, st, tbase, rbase, pd, npairs,
+                               max_side, slots, tasks_per_slot, slot_floats, t_floats, min_std, min_mean_diff,
+                               out_max, out_argmax, surfaces, surf_off);
+        }
     } else {
         const size_t lds = elems * sizeof(double);
         if (lds > 64 * 1024) {
