@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libsvamd.so')
+# SVAMD_LIBRARY selects another build of the library (A/B measurements)
+LIB_PATH = os.environ.get('SVAMD_LIBRARY') or os.path.join(_HERE, 'libsvamd.so')
 
 OK, ERR_INVALID, ERR_SHAPE, ERR_WORKSPACE, ERR_HIP, ERR_LIMIT = range(6)
 U8, F32, F64 = 0, 1, 2

@@ -295,31 +295,64 @@ template <int G>
 __device__ __forceinline__ void pair_row(pf2 (&acc)[G], const float *__restrict__ trow,
                                          const float *__restrict__ srow, int groups)
 {
+    // the window's quads rotate through q0, q1, q2 (q0, q1 for G = 4); whole rotations
+    // in the loop, so that every register is back in its role at the loop's end
     ColQuad q0 = load_colquad(srow), q1, q2;
+    const pf4 *t4 = reinterpret_cast<const pf4 *>(trow);
     int g = 0;
     if constexpr (G == 8) {
+        // four quads in rotation: the quad and the template values of the NEXT group are
+        // requested before the current group's FMAs, so one wavefront alone hides the
+        // LDS latency
+        ColQuad q3;
         q1 = load_colquad(srow + 8);
-        for (;;) {
-            q2 = load_colquad(srow + 8 * (g + 2));
-            pair_group<G>(acc, *reinterpret_cast<const pf4 *>(trow + 4 * g), q0, q1, q2);
-            if (++g >= groups) break;
-            q0 = load_colquad(srow + 8 * (g + 2));
-            pair_group<G>(acc, *reinterpret_cast<const pf4 *>(trow + 4 * g), q1, q2, q0);
-            if (++g >= groups) break;
-            q1 = load_colquad(srow + 8 * (g + 2));
-            pair_group<G>(acc, *reinterpret_cast<const pf4 *>(trow + 4 * g), q2, q0, q1);
-            if (++g >= groups) break;
+        q2 = load_colquad(srow + 16);
+        pf4 ta = t4[0], tb;
+        for (; g + 4 <= groups; g += 4) {
+            q3 = load_colquad(srow + 8 * (g + 3));
+            tb = t4[g + 1];
+            pair_group<G>(acc, ta, q0, q1, q2);
+            q0 = load_colquad(srow + 8 * (g + 4));
+            ta = t4[g + 2];
+            pair_group<G>(acc, tb, q1, q2, q3);
+            q1 = load_colquad(srow + 8 * (g + 5));
+            tb = t4[g + 3];
+            pair_group<G>(acc, ta, q2, q3, q0);
+            q2 = load_colquad(srow + 8 * (g + 6));
+            ta = t4[g + 4];
+            pair_group<G>(acc, tb, q3, q0, q1);
+        }
+        if (g < groups) {
+            q3 = load_colquad(srow + 8 * (g + 3));
+            tb = t4[g + 1];
+            pair_group<G>(acc, ta, q0, q1, q2);
+            if (g + 1 < groups) {
+                q0 = load_colquad(srow + 8 * (g + 4));
+                ta = t4[g + 2];
+                pair_group<G>(acc, tb, q1, q2, q3);
+                if (g + 2 < groups)
+                    pair_group<G>(acc, ta, q2, q3, q0);
+            }
         }
     } else {
-        for (;;) {
+        for (; g + 2 <= groups; g += 2) {
             q1 = load_colquad(srow + 8 * (g + 1));
-            pair_group<G>(acc, *reinterpret_cast<const pf4 *>(trow + 4 * g), q0, q1, q1);
-            if (++g >= groups) break;
-            q0 = load_colquad(srow + 8 * (g + 1));
-            pair_group<G>(acc, *reinterpret_cast<const pf4 *>(trow + 4 * g), q1, q0, q0);
-            if (++g >= groups) break;
+            pair_group<G>(acc, t4[g], q0, q1, q1);
+            q0 = load_colquad(srow + 8 * (g + 2));
+            pair_group<G>(acc, t4[g + 1], q1, q0, q0);
+        }
+        if (g < groups) {
+            q1 = load_colquad(srow + 8 * (g + 1));
+            pair_group<G>(acc, t4[g], q0, q1, q1);
         }
     }
+}
+
+// Row pitch (in columns) of the row-pair image S: the padded surface columns, the
+// padded template width and the quads the window prefetch reads ahead.
+__host__ __device__ __forceinline__ int pair_row_pitch(int gcols, int mwp)
+{
+    return (gcols + mwp + 12 + 3) & ~3;
 }
 
 struct SlotInfo {
@@ -349,7 +382,7 @@ template <int G>
 __global__ void __launch_bounds__(WAVE)
 scan_pairs_f32_kernel(const double *__restrict__ tbase, const double *__restrict__ rbase,
                       const PairDesc *__restrict__ desc, int64_t npairs, int max_side, int slots,
-                      int tasks_per_slot, int slot_floats, int t_floats, double min_std,
+                      int tasks_per_slot, int slot_floats, int t_floats, int s_floats, double min_std,
                       double min_mean_diff, double *__restrict__ out_max, int64_t *__restrict__ out_argmax,
                       double *__restrict__ surfaces, const int64_t *__restrict__ surf_off)
 {
@@ -357,6 +390,7 @@ scan_pairs_f32_kernel(const double *__restrict__ tbase, const double *__restrict
     __shared__ SlotInfo info[PAIR_MAX_SLOTS];
     float *lds = reinterpret_cast<float *>(smem_raw);
     const int lane = threadIdx.x;
+    const int tstride = (max_side + 3) & ~3;     // template row stride in every slot
 
     for (int64_t base = (int64_t)blockIdx.x * slots; base < npairs; base += (int64_t)gridDim.x * slots) {
         __syncthreads();   // LDS reuse across iterations
@@ -379,26 +413,42 @@ scan_pairs_f32_kernel(const double *__restrict__ tbase, const double *__restrict
             const double *T = tbase + d.t_off;
             const double *R = rbase + d.r_off;
             const int tn = th * tw, rn = rh * rw;
+            const int mh = min(th, rh), mw = min(tw, rw);
+            const int mwp = (mw + 3) & ~3;
+            const int gcols = (rw + G - 1) / G * G;
+            const int rxp = pair_row_pitch(gcols, mwp);
+            float *Ts = lds + (size_t)s * slot_floats, *Ss = Ts + t_floats, *Ps = Ss + s_floats;
+            const unsigned tdiv = tw > 1 ? (unsigned)(((1ull << 32) + tw - 1) / tw) : 0u;
+            const unsigned rdiv = rw > 1 ? (unsigned)(((1ull << 32) + rw - 1) / rw) : 0u;
+            // pass 1: means
             double ts = 0.0, rs = 0.0;
             for (int i = lane; i < tn; i += WAVE) {
-                const int y = i / tw, x = i - y * tw;
+                const int y = tw > 1 ? (int)__umulhi((unsigned)i, tdiv) : i, x = i - y * tw;
                 ts += T[y * d.t_pitch + x];
             }
             for (int i = lane; i < rn; i += WAVE) {
-                const int y = i / rw, x = i - y * rw;
+                const int y = rw > 1 ? (int)__umulhi((unsigned)i, rdiv) : i, x = i - y * rw;
                 rs += R[y * d.r_pitch + x];
             }
             const double tmean = wave_sum(ts) / (double)tn, rmean = wave_sum(rs) / (double)rn;
+            // pass 2: squared deviations; the centred values go to LDS on the way.  The
+            // template slot is zero beyond the pair's own rows and columns: every lane of
+            // the wavefront walks the same number of rows and column groups.
+            for (int i = lane; i < t_floats; i += WAVE)
+                Ts[i] = 0.0f;
             double tq = 0.0, rq = 0.0;
             for (int i = lane; i < tn; i += WAVE) {
-                const int y = i / tw, x = i - y * tw;
+                const int y = tw > 1 ? (int)__umulhi((unsigned)i, tdiv) : i, x = i - y * tw;
                 const double v = T[y * d.t_pitch + x] - tmean;
                 tq += v * v;
+                if (y < mh && x < mw)
+                    Ts[y * tstride + x] = (float)v;
             }
             for (int i = lane; i < rn; i += WAVE) {
-                const int y = i / rw, x = i - y * rw;
+                const int y = rw > 1 ? (int)__umulhi((unsigned)i, rdiv) : i, x = i - y * rw;
                 const double v = R[y * d.r_pitch + x] - rmean;
                 rq += v * v;
+                Ps[i] = (float)v;
             }
             const double tstd = sqrt(wave_sum(tq) / (double)tn), rstd = sqrt(wave_sum(rq) / (double)rn);
             const bool flat = tstd < min_std;
@@ -415,89 +465,106 @@ scan_pairs_f32_kernel(const double *__restrict__ tbase, const double *__restrict
             }
             if (flat)
                 continue;
-            const int mh = min(th, rh), mw = min(tw, rw);
-            const int mwp = (mw + 3) & ~3;
-            const int gcols = (rw + G - 1) / G * G;
-            const int rxp = (gcols + mwp + 8 + 3) & ~3;
-            float *Ts = lds + (size_t)s * slot_floats, *Ss = Ts + t_floats;
-            for (int i = lane; i < mh * mwp; i += WAVE) {
-                const int y = i / mwp, x = i - y * mwp;
-                Ts[i] = x < mw ? (float)(T[y * d.t_pitch + x] - tmean) : 0.0f;
-            }
-            for (int i = lane; i < rh * rxp; i += WAVE) {
-                const int a = i / rxp, x = i - a * rxp;
-                const int xs = x % rw, a1 = a + 1 < rh ? a + 1 : 0;
-                Ss[2 * i] = (float)(R[a * d.r_pitch + xs] - rmean);
-                Ss[2 * i + 1] = (float)(R[a1 * d.r_pitch + xs] - rmean);
+            // S[a][x] = (r'[a][x mod rw], r'[(a + 1) mod rh][x mod rw]) from the plain copy
+            for (int x = lane; x < rxp; x += WAVE) {
+                const int xs = x % rw;
+                float cur = Ps[xs];
+                for (int a = 0; a < rh; ++a) {
+                    const float nxt = Ps[(a + 1 < rh ? a + 1 : 0) * rw + xs];
+                    *reinterpret_cast<pf2 *>(Ss + 2 * (a * rxp + x)) = pf2{cur, nxt};
+                    cur = nxt;
+                }
             }
         }
         __syncthreads();
 
         // ---- the surfaces: lane -> (slot, task) ----
+        // Loop bounds are made wave-uniform (the largest row / column-group / task
+        // count among the wavefront's pairs): lanes of smaller pairs multiply the
+        // zeros of their template slot, lanes without a task compute on their
+        // slot's first task and drop the result.  No divergent control flow inside.
         const int slot = slots > 1 ? lane / tasks_per_slot : 0;
         const int first_task = slots > 1 ? lane - slot * tasks_per_slot : lane;
-        const int task_step = slots > 1 ? 0x40000000 : WAVE;
+        const bool evaluate = slot < slots && info[slot].state == 0;
+        SlotInfo si;
+        si.th = si.tw = 0;
+        si.rh = si.rw = 1;
+        si.tstd = si.rstd = si.tmean = si.rmean = 0.0;
+        if (evaluate)
+            si = info[slot];
+        const int mh = min(si.th, si.rh), mw = min(si.tw, si.rw);
+        const int mwp = (mw + 3) & ~3;
+        const int lgroups = (si.rw + G - 1) / G;
+        const int rxp = evaluate ? pair_row_pitch(lgroups * G, mwp) : 0;
+        const int ntasks = evaluate ? (si.rh + 1) / 2 * lgroups : 0;
+        int u_rows = mh, u_groups = mwp / 4, u_tasks = ntasks;
+#pragma unroll
+        for (int o = WAVE / 2; o > 0; o >>= 1) {
+            u_rows = max(u_rows, __shfl_xor(u_rows, o, WAVE));
+            u_groups = max(u_groups, __shfl_xor(u_groups, o, WAVE));
+            u_tasks = max(u_tasks, __shfl_xor(u_tasks, o, WAVE));
+        }
+        u_rows = __builtin_amdgcn_readfirstlane(u_rows);
+        u_groups = __builtin_amdgcn_readfirstlane(u_groups);
+        u_tasks = __builtin_amdgcn_readfirstlane(u_tasks);
+        const int rounds = slots > 1 ? (u_tasks > 0 ? 1 : 0) : (u_tasks + WAVE - 1) / WAVE;
+        const int flush_rows = u_groups * 4 >= PAIR_FLUSH ? 1 : PAIR_FLUSH / max(u_groups * 4, 1);
+
         BestNan mine;
         mine.best = -INFINITY;
         mine.arg = 0x7fffffff;
         mine.has_nan = 0;
-        if (slot < slots && info[slot].state == 0) {
-            const SlotInfo si = info[slot];
-            const int64_t p = base + slot;
-            const int mh = min(si.th, si.rh), mw = min(si.tw, si.rw);
-            const int mwp = (mw + 3) & ~3;
-            const int lgroups = (si.rw + G - 1) / G;
-            const int rxp = (lgroups * G + mwp + 8 + 3) & ~3;
-            const int ntasks = (si.rh + 1) / 2 * lgroups;
-            const int tn = si.th * si.tw;
-            const float *Ts = lds + (size_t)slot * slot_floats, *Ss = Ts + t_floats;
-            const double scale = tn == 0 ? ((si.rstd > 0.0) ? 0.0 : NAN) : 1.0 / (si.tstd * (double)tn) / si.rstd;
-            double *surf = surfaces ? surfaces + surf_off[p] : nullptr;
-            const int flush_rows = mwp >= PAIR_FLUSH ? 1 : PAIR_FLUSH / (mwp > 0 ? mwp : 1);
-            for (int task = first_task; task < ntasks; task += task_step) {
-                const int kp = task / lgroups, l0 = (task - kp * lgroups) * G, k = 2 * kp;
-                pf2 acc[G];
-                double d0[G], d1[G];
+        const int slot_c = slot < slots ? slot : 0;
+        const float *Ts = lds + (size_t)slot_c * slot_floats, *Ss = Ts + t_floats;
+        const int tn = si.th * si.tw;
+        const double scale = tn == 0 ? ((si.rstd > 0.0) ? 0.0 : NAN) : 1.0 / (si.tstd * (double)tn) / si.rstd;
+        double *surf = (surfaces && evaluate) ? surfaces + surf_off[base + slot] : nullptr;
+        for (int round = 0; round < rounds; ++round) {
+            const int task = first_task + round * WAVE;
+            const bool has_task = evaluate && task < ntasks;
+            const int tk = has_task ? task : 0;
+            const int kp = tk / lgroups, l0 = (tk - kp * lgroups) * G, k = 2 * kp;
+            pf2 acc[G];
+            double d0[G], d1[G];
 #pragma unroll
-                for (int j = 0; j < G; ++j) {
-                    acc[j] = pf2{0.f, 0.f};
-                    d0[j] = d1[j] = 0.0;
-                }
-                int since = 0;
-                for (int m = 0; m < mh; ++m) {
-                    int a = k + m;
-                    if (a >= si.rh)
-                        a -= si.rh;
-                    if (mwp > 0)
-                        pair_row<G>(acc, Ts + m * mwp, Ss + 2 * (a * rxp + l0), mwp / 4);
-                    if (++since == flush_rows || m == mh - 1) {
-                        since = 0;
-#pragma unroll
-                        for (int j = 0; j < G; ++j) {
-                            d0[j] += (double)acc[j].x;
-                            d1[j] += (double)acc[j].y;
-                            acc[j] = pf2{0.f, 0.f};
-                        }
-                    }
-                }
-#pragma unroll
-                for (int row = 0; row < 2; ++row) {
-                    if (k + row >= si.rh)
-                        continue;
+            for (int j = 0; j < G; ++j) {
+                acc[j] = pf2{0.f, 0.f};
+                d0[j] = d1[j] = 0.0;
+            }
+            int since = 0, a = k < si.rh ? k : 0;
+            for (int m = 0; m < u_rows; ++m) {
+                if (u_groups > 0)
+                    pair_row<G>(acc, Ts + m * tstride, Ss + 2 * (a * rxp + l0), u_groups);
+                a = a + 1 == si.rh ? 0 : a + 1;
+                if (++since == flush_rows || m == u_rows - 1) {
+                    since = 0;
 #pragma unroll
                     for (int j = 0; j < G; ++j) {
-                        if (l0 + j >= si.rw)
-                            continue;
-                        const int idx = (k + row) * si.rw + l0 + j;
-                        const double v = tn == 0 ? scale : (row ? d1[j] : d0[j]) * scale;
-                        if (surf)
-                            surf[idx] = v;
-                        if (isnan(v)) {
-                            mine.has_nan = 1;
-                        } else if (v > mine.best || (v == mine.best && idx < mine.arg)) {
-                            mine.best = v;
-                            mine.arg = idx;
-                        }
+                        d0[j] += (double)acc[j].x;
+                        d1[j] += (double)acc[j].y;
+                        acc[j] = pf2{0.f, 0.f};
+                    }
+                }
+            }
+            if (!has_task)
+                continue;
+#pragma unroll
+            for (int row = 0; row < 2; ++row) {
+                if (k + row >= si.rh)
+                    continue;
+#pragma unroll
+                for (int j = 0; j < G; ++j) {
+                    if (l0 + j >= si.rw)
+                        continue;
+                    const int idx = (k + row) * si.rw + l0 + j;
+                    const double v = tn == 0 ? scale : (row ? d1[j] : d0[j]) * scale;
+                    if (surf)
+                        surf[idx] = v;
+                    if (isnan(v)) {
+                        mine.has_nan = 1;
+                    } else if (v > mine.best || (v == mine.best && idx < mine.arg)) {
+                        mine.best = v;
+                        mine.arg = idx;
                     }
                 }
             }
@@ -607,8 +674,9 @@ extern "C" int svamd_scan_pairs(const double *tbase, const double *rbase, const 
         const int G = cols8 == cols4 ? 8 : 4;
         const int gcols = G == 8 ? cols8 : cols4;
         const int t_floats = max_side * (int)side4;
-        const int rxp = (gcols + (int)side4 + 8 + 3) & ~3;
-        const int slot_floats = t_floats + 2 * max_side * rxp;
+        const int rxp = pair_row_pitch(gcols, (int)side4);
+        const int s_floats = 2 * max_side * rxp;
+        const int slot_floats = t_floats + s_floats + max_side * (int)side4;   // template, row pairs, plain region
         const int tasks_per_slot = (max_side + 1) / 2 * (gcols / G);
         int slots = WAVE / tasks_per_slot;
         if (slots < 1) slots = 1;
@@ -624,7 +692,7 @@ extern "C" int svamd_scan_pairs(const double *tbase, const double *rbase, const 
                 raised8 = true;
             }
             hipLaunchKernelGGL((scan_pairs_f32_kernel<8>), dim3(fgrid), dim3(WAVE), lds, st, tbase, rbase, pd, npairs,
-                               max_side, slots, tasks_per_slot, slot_floats, t_floats, min_std, min_mean_diff,
+                               max_side, slots, tasks_per_slot, slot_floats, t_floats, s_floats, min_std, min_mean_diff,
                                out_max, out_argmax, surfaces, surf_off);
         } else {
             if (lds > 64 * 1024 && !raised4) {
@@ -633,7 +701,7 @@ extern "C" int svamd_scan_pairs(const double *tbase, const double *rbase, const 
                 raised4 = true;
             }
             hipLaunchKernelGGL((scan_pairs_f32_kernel<4>), dim3(fgrid), dim3(WAVE), lds, st, tbase, rbase, pd, npairs,
-                               max_side, slots, tasks_per_slot, slot_floats, t_floats, min_std, min_mean_diff,
+                               max_side, slots, tasks_per_slot, slot_floats, t_floats, s_floats, min_std, min_mean_diff,
                                out_max, out_argmax, surfaces, surf_off);
         }
     } else {
