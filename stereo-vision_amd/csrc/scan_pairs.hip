@@ -335,15 +335,26 @@ __device__ __forceinline__ void pair_row(pf2 (&acc)[G], const float *__restrict_
             }
         }
     } else {
-        for (; g + 2 <= groups; g += 2) {
-            q1 = load_colquad(srow + 8 * (g + 1));
-            pair_group<G>(acc, t4[g], q0, q1, q1);
-            q0 = load_colquad(srow + 8 * (g + 2));
-            pair_group<G>(acc, t4[g + 1], q1, q0, q0);
+        // G = 4: two quads per group, three in rotation (one requested ahead)
+        q1 = load_colquad(srow + 8);
+        pf4 ta = t4[0], tb, tc;
+        for (; g + 3 <= groups; g += 3) {
+            q2 = load_colquad(srow + 8 * (g + 2));
+            tb = t4[g + 1];
+            pair_group<G>(acc, ta, q0, q1, q1);
+            q0 = load_colquad(srow + 8 * (g + 3));
+            tc = t4[g + 2];
+            pair_group<G>(acc, tb, q1, q2, q2);
+            q1 = load_colquad(srow + 8 * (g + 4));
+            ta = t4[g + 3];
+            pair_group<G>(acc, tc, q2, q0, q0);
         }
         if (g < groups) {
-            q1 = load_colquad(srow + 8 * (g + 1));
-            pair_group<G>(acc, t4[g], q0, q1, q1);
+            q2 = load_colquad(srow + 8 * (g + 2));
+            tb = t4[g + 1];
+            pair_group<G>(acc, ta, q0, q1, q1);
+            if (g + 1 < groups)
+                pair_group<G>(acc, tb, q1, q2, q2);
         }
     }
 }
@@ -378,8 +389,14 @@ __device__ __forceinline__ BestNan wave_best(BestNan v)
     return v;
 }
 
+// Sum over the workgroup: one wavefront needs no LDS round trip.
+__device__ __forceinline__ double pair_sum(double v, double *red, int nthr)
+{
+    return nthr > WAVE ? block_sum(v, red) : wave_sum(v);
+}
+
 template <int G>
-__global__ void __launch_bounds__(WAVE)
+__global__ void __launch_bounds__(2 * WAVE)
 scan_pairs_f32_kernel(const double *__restrict__ tbase, const double *__restrict__ rbase,
                       const PairDesc *__restrict__ desc, int64_t npairs, int max_side, int slots,
                       int tasks_per_slot, int slot_floats, int t_floats, int s_floats, double min_std,
@@ -388,8 +405,13 @@ scan_pairs_f32_kernel(const double *__restrict__ tbase, const double *__restrict
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     __shared__ SlotInfo info[PAIR_MAX_SLOTS];
+    __shared__ double red[17];
+    __shared__ double red_d[4];
+    __shared__ int red_i[8];
     float *lds = reinterpret_cast<float *>(smem_raw);
-    const int lane = threadIdx.x;
+    // 64 threads when several pairs share the wavefront, 128 (two wavefronts on one
+    // pair) otherwise; `lane` is the thread's index in the workgroup
+    const int lane = threadIdx.x, nthr = blockDim.x;
     const int tstride = (max_side + 3) & ~3;     // template row stride in every slot
 
     for (int64_t base = (int64_t)blockIdx.x * slots; base < npairs; base += (int64_t)gridDim.x * slots) {
@@ -420,37 +442,38 @@ scan_pairs_f32_kernel(const double *__restrict__ tbase, const double *__restrict
             float *Ts = lds + (size_t)s * slot_floats, *Ss = Ts + t_floats, *Ps = Ss + s_floats;
             const unsigned tdiv = tw > 1 ? (unsigned)(((1ull << 32) + tw - 1) / tw) : 0u;
             const unsigned rdiv = rw > 1 ? (unsigned)(((1ull << 32) + rw - 1) / rw) : 0u;
+            // The template slot is zero beyond the pair's own rows and columns: every lane
+            // of the wavefront walks the same number of rows and column groups.
+            for (int i = lane; i < t_floats; i += nthr)
+                Ts[i] = 0.0f;
             // pass 1: means
             double ts = 0.0, rs = 0.0;
-            for (int i = lane; i < tn; i += WAVE) {
+            for (int i = lane; i < tn; i += nthr) {
                 const int y = tw > 1 ? (int)__umulhi((unsigned)i, tdiv) : i, x = i - y * tw;
                 ts += T[y * d.t_pitch + x];
             }
-            for (int i = lane; i < rn; i += WAVE) {
+            for (int i = lane; i < rn; i += nthr) {
                 const int y = rw > 1 ? (int)__umulhi((unsigned)i, rdiv) : i, x = i - y * rw;
                 rs += R[y * d.r_pitch + x];
             }
-            const double tmean = wave_sum(ts) / (double)tn, rmean = wave_sum(rs) / (double)rn;
-            // pass 2: squared deviations; the centred values go to LDS on the way.  The
-            // template slot is zero beyond the pair's own rows and columns: every lane of
-            // the wavefront walks the same number of rows and column groups.
-            for (int i = lane; i < t_floats; i += WAVE)
-                Ts[i] = 0.0f;
+            const double tmean = pair_sum(ts, red, nthr) / (double)tn, rmean = pair_sum(rs, red, nthr) / (double)rn;
+            // pass 2: squared deviations; the centred values go to LDS on the way (the
+            // reductions in between order them after the zero fill)
             double tq = 0.0, rq = 0.0;
-            for (int i = lane; i < tn; i += WAVE) {
+            for (int i = lane; i < tn; i += nthr) {
                 const int y = tw > 1 ? (int)__umulhi((unsigned)i, tdiv) : i, x = i - y * tw;
                 const double v = T[y * d.t_pitch + x] - tmean;
                 tq += v * v;
                 if (y < mh && x < mw)
                     Ts[y * tstride + x] = (float)v;
             }
-            for (int i = lane; i < rn; i += WAVE) {
+            for (int i = lane; i < rn; i += nthr) {
                 const int y = rw > 1 ? (int)__umulhi((unsigned)i, rdiv) : i, x = i - y * rw;
                 const double v = R[y * d.r_pitch + x] - rmean;
                 rq += v * v;
                 Ps[i] = (float)v;
             }
-            const double tstd = sqrt(wave_sum(tq) / (double)tn), rstd = sqrt(wave_sum(rq) / (double)rn);
+            const double tstd = sqrt(pair_sum(tq, red, nthr) / (double)tn), rstd = sqrt(pair_sum(rq, red, nthr) / (double)rn);
             const bool flat = tstd < min_std;
             if (lane == 0) {
                 info[s].tmean = tmean;
@@ -466,7 +489,7 @@ scan_pairs_f32_kernel(const double *__restrict__ tbase, const double *__restrict
             if (flat)
                 continue;
             // S[a][x] = (r'[a][x mod rw], r'[(a + 1) mod rh][x mod rw]) from the plain copy
-            for (int x = lane; x < rxp; x += WAVE) {
+            for (int x = lane; x < rxp; x += nthr) {
                 const int xs = x % rw;
                 float cur = Ps[xs];
                 for (int a = 0; a < rh; ++a) {
@@ -507,7 +530,7 @@ scan_pairs_f32_kernel(const double *__restrict__ tbase, const double *__restrict
         u_rows = __builtin_amdgcn_readfirstlane(u_rows);
         u_groups = __builtin_amdgcn_readfirstlane(u_groups);
         u_tasks = __builtin_amdgcn_readfirstlane(u_tasks);
-        const int rounds = slots > 1 ? (u_tasks > 0 ? 1 : 0) : (u_tasks + WAVE - 1) / WAVE;
+        const int rounds = slots > 1 ? (u_tasks > 0 ? 1 : 0) : (u_tasks + nthr - 1) / nthr;
         const int flush_rows = u_groups * 4 >= PAIR_FLUSH ? 1 : PAIR_FLUSH / max(u_groups * 4, 1);
 
         BestNan mine;
@@ -520,7 +543,7 @@ scan_pairs_f32_kernel(const double *__restrict__ tbase, const double *__restrict
         const double scale = tn == 0 ? ((si.rstd > 0.0) ? 0.0 : NAN) : 1.0 / (si.tstd * (double)tn) / si.rstd;
         double *surf = (surfaces && evaluate) ? surfaces + surf_off[base + slot] : nullptr;
         for (int round = 0; round < rounds; ++round) {
-            const int task = first_task + round * WAVE;
+            const int task = first_task + round * nthr;
             const bool has_task = evaluate && task < ntasks;
             const int tk = has_task ? task : 0;
             const int kp = tk / lgroups, l0 = (tk - kp * lgroups) * G, k = 2 * kp;
@@ -582,7 +605,7 @@ scan_pairs_f32_kernel(const double *__restrict__ tbase, const double *__restrict
                     v.arg = 0x7fffffff;
                     v.has_nan = 0;
                 }
-                v = wave_best(v);
+                v = nthr > WAVE ? block_best(v, red_d, red_i) : wave_best(v);
                 if (lane == 0) {
                     out_max[p] = v.has_nan ? NAN : v.best;
                     if (out_argmax)
@@ -592,7 +615,7 @@ scan_pairs_f32_kernel(const double *__restrict__ tbase, const double *__restrict
                 const double fill = fabs(info[s].tmean - info[s].rmean) < min_mean_diff ? 1.0 : 0.0;
                 if (surfaces) {
                     double *surf = surfaces + surf_off[p];
-                    for (int i = lane; i < info[s].rh * info[s].rw; i += WAVE)
+                    for (int i = lane; i < info[s].rh * info[s].rw; i += nthr)
                         surf[i] = fill;
                 }
                 if (lane == 0) {
@@ -670,16 +693,21 @@ extern "C" int svamd_scan_pairs(const double *tbase, const double *rbase, const 
     const PairDesc *pd = reinterpret_cast<const PairDesc *>(desc);
     if (acc_precision == SVAMD_ACC_F32) {
         // columns per task: 8 unless 4 wastes fewer padded columns
+        // Pairs with more than 32 tasks of 8 columns get a workgroup of two wavefronts
+        // and tasks of 4 columns: their LDS slot leaves room for few workgroups per CU,
+        // and a SIMD that holds a single wavefront cannot hide its LDS latency.
         const int cols4 = (max_side + 3) / 4 * 4, cols8 = (max_side + 7) / 8 * 8;
-        const int G = cols8 == cols4 ? 8 : 4;
+        const bool two_waves = (max_side + 1) / 2 * (cols8 / 8) > WAVE / 2;
+        const int G = (cols8 == cols4 && !two_waves) ? 8 : 4;
         const int gcols = G == 8 ? cols8 : cols4;
         const int t_floats = max_side * (int)side4;
         const int rxp = pair_row_pitch(gcols, (int)side4);
         const int s_floats = 2 * max_side * rxp;
         const int slot_floats = t_floats + s_floats + max_side * (int)side4;   // template, row pairs, plain region
         const int tasks_per_slot = (max_side + 1) / 2 * (gcols / G);
-        int slots = WAVE / tasks_per_slot;
+        int slots = two_waves ? 1 : WAVE / tasks_per_slot;
         if (slots < 1) slots = 1;
+        const int fthreads = two_waves ? 2 * WAVE : WAVE;
         if (slots > PAIR_MAX_SLOTS) slots = PAIR_MAX_SLOTS;
         const size_t lds = (size_t)slots * slot_floats * sizeof(float);
         const int64_t groups = (npairs + slots - 1) / slots;
@@ -691,7 +719,7 @@ extern "C" int svamd_scan_pairs(const double *tbase, const double *rbase, const 
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
                 raised8 = true;
             }
-            hipLaunchKernelGGL((scan_pairs_f32_kernel<8>), dim3(fgrid), dim3(WAVE), lds, st, tbase, rbase, pd, npairs,
+            hipLaunchKernelGGL((scan_pairs_f32_kernel<8>), dim3(fgrid), dim3(fthreads), lds, st, tbase, rbase, pd, npairs,
                                max_side, slots, tasks_per_slot, slot_floats, t_floats, s_floats, min_std, min_mean_diff,
                                out_max, out_argmax, surfaces, surf_off);
         } else {
@@ -700,7 +728,7 @@ extern "C" int svamd_scan_pairs(const double *tbase, const double *rbase, const 
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
                 raised4 = true;
             }
-            hipLaunchKernelGGL((scan_pairs_f32_kernel<4>), dim3(fgrid), dim3(WAVE), lds, st, tbase, rbase, pd, npairs,
+            hipLaunchKernelGGL((scan_pairs_f32_kernel<4>), dim3(fgrid), dim3(fthreads), lds, st, tbase, rbase, pd, npairs,
                                max_side, slots, tasks_per_slot, slot_floats, t_floats, s_floats, min_std, min_mean_diff,
                                out_max, out_argmax, surfaces, surf_off);
         }
