@@ -323,28 +323,33 @@ __device__ __forceinline__ void accumulate_any(const float *__restrict__ lp, con
 {
     static_assert(D <= 9, "three right quads cover offsets 0..8 only");
     const int groups = (win_w + BAND_X - 1 + 3) / 4;
-    const int first_interior = 1, last_interior = (win_w - 4) / 4;   // groups c with 3 <= 4c and 4c + 3 <= win_w - 1
-    auto step = [&](int c, const Quad &r0, const Quad &r1, const Quad &r2) {
-        const Quad lq = load_quad<true>(lp + 4 * c);
-        if (c >= first_interior && c <= last_interior && win_w >= 4)
-            quad_any<D, true>(acc, lq, r0, r1, r2, 4 * c, win_w);
-        else
-            quad_any<D, false>(acc, lq, r0, r1, r2, 4 * c, win_w);
-    };
+    // groups c = 1 .. last_interior lie inside all four windows (3 <= 4c, 4c + 3 <= win_w - 1)
+    const int last_interior = win_w >= 8 ? (win_w - 4) / 4 : 0;
+    // The row has three phases, none with a branch inside a loop over accumulators:
+    // the first group (masked), whole rotations of three interior groups (the three
+    // right quads change roles without copies), and the remaining groups (masked
+    // code, which also serves interior groups, with the quads moved down by one).
+    const int rotations = last_interior / 3;
 #pragma unroll 1
     for (int a = 0; a < rows; ++a) {
-        Quad r0 = load_quad<ALIGNED>(rp), r1 = load_quad<ALIGNED>(rp + 4), r2;
-        int c = 0;
-        for (;;) {
+        Quad r0 = load_quad<ALIGNED>(rp), r1 = load_quad<ALIGNED>(rp + 4), r2 = load_quad<ALIGNED>(rp + 8);
+        quad_any<D, false>(acc, load_quad<true>(lp), r0, r1, r2, 0, win_w);
+        r0 = r1;
+        r1 = r2;
+        int c = 1;
+        for (int t = 0; t < rotations; ++t, c += 3) {
             r2 = load_quad<ALIGNED>(rp + 4 * (c + 2));
-            step(c, r0, r1, r2);
-            if (++c >= groups) break;
-            r0 = load_quad<ALIGNED>(rp + 4 * (c + 2));
-            step(c, r1, r2, r0);
-            if (++c >= groups) break;
-            r1 = load_quad<ALIGNED>(rp + 4 * (c + 2));
-            step(c, r2, r0, r1);
-            if (++c >= groups) break;
+            quad_any<D, true>(acc, load_quad<true>(lp + 4 * c), r0, r1, r2, 4 * c, win_w);
+            r0 = load_quad<ALIGNED>(rp + 4 * (c + 3));
+            quad_any<D, true>(acc, load_quad<true>(lp + 4 * c + 4), r1, r2, r0, 4 * c + 4, win_w);
+            r1 = load_quad<ALIGNED>(rp + 4 * (c + 4));
+            quad_any<D, true>(acc, load_quad<true>(lp + 4 * c + 8), r2, r0, r1, 4 * c + 8, win_w);
+        }
+        for (; c < groups; ++c) {
+            r2 = load_quad<ALIGNED>(rp + 4 * (c + 2));
+            quad_any<D, false>(acc, load_quad<true>(lp + 4 * c), r0, r1, r2, 4 * c, win_w);
+            r0 = r1;
+            r1 = r2;
         }
         lp += lpitch;
         rp += rpitch;
