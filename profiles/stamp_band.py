@@ -43,3 +43,20 @@ for blk in full[[1000, 2500]]:
     for w in (0, 4, 8, 12):
         t = (b[w, :33] - t0) / 1e5
         print('  wave %2d pass end (ms):' % w, np.round(t[[1, 2, 4, 8, 12, 16, 20, 24, 28, 32]], 3))
+
+# per-block accounting over all full blocks: where a wavefront's share of the block time goes
+b = s[full].astype(np.float64)
+t0 = b[:, :, 0].min(axis=1, keepdims=True)
+first, last = b[:, :, 1] - t0, b[:, :, 32] - t0          # end of pass 1 / of pass 32, per wavefront
+block = last.max(axis=1, keepdims=True)
+per_pass = (last - first) / 31.0
+lead_in = first - per_pass                                # entry -> start of the first 8-offset pass
+print('per block (mean over blocks and wavefronts), share of the block duration:')
+print('  staging + centre pass before the first pass : %.3f' % np.mean(lead_in / block))
+print('  32 passes                                   : %.3f' % np.mean((last - lead_in) / block))
+print('  waiting for the slowest wavefront at the end : %.3f' % np.mean((block - last) / block))
+print('  spread of pass time between wavefronts (max/min per block): %.3f' % np.mean(per_pass.max(1) / per_pass.min(1)))
+for blk in full[[1000, 2500]]:
+    bb = s[blk]
+    print('block', blk, 'end of pass 32 per wavefront (ms):', np.round((bb[:, 32] - bb[:, 0].min()) / 1e5, 2))
+    print('          end of pass 8  per wavefront (ms):', np.round((bb[:, 8] - bb[:, 0].min()) / 1e5, 2))
