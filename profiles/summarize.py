@@ -15,8 +15,8 @@ def main(root):
     stats = os.path.join(root, 'stats', 'stats_results.db')
     if os.path.exists(stats):
         db = sqlite3.connect(stats)
-        print('== rocprofv3 --kernel-trace --stats (durations in ns) ==')
-        print(f'{"calls":>6} {"total_ns":>14} {"avg_ns":>14} {"pct":>7}  kernel')
+        print('== rocprofv3 --kernel-trace --stats (durations in microseconds) ==')
+        print(f'{"calls":>6} {"total_us":>14} {"avg_us":>14} {"pct":>7}  kernel')
         for name, calls, total, avg, pct in db.execute(
                 'select name, total_calls, total_duration, average, percentage from top_kernels'):
             print(f'{calls:>6} {total:>14.0f} {avg:>14.1f} {pct:>7.2f}  {name[:110]}')

@@ -370,8 +370,6 @@ __device__ __forceinline__ void accumulate_rows(const float *__restrict__ lp, co
 }
 
 struct LaneState {
-    double s1l[BAND_X];    // sum of (L - 128) over the window
-    double invl[BAND_X];   // 1 / sqrt(A_L)
     double best[BAND_X];
     int arg[BAND_X];
 };
@@ -382,6 +380,8 @@ struct LaneState {
 template <int D>
 __device__ __forceinline__ void finish_pass(const BandGeom &g, const float2v (&acc)[BAND_X / 2][D], int k0,
                                             int kend, bool centre_pass, int wy, int xbase,
+                                            const int32_t *__restrict__ wsum_l,
+                                            const double *__restrict__ winv_l,
                                             const int32_t *__restrict__ wsum_r,
                                             const double *__restrict__ winv_r, LaneState &st,
                                             double *__restrict__ scores)
@@ -392,6 +392,10 @@ __device__ __forceinline__ void finish_pass(const BandGeom &g, const float2v (&a
     for (int x = 0; x < BAND_X; ++x) {
         const int xw = xbase + x;
         const bool wvalid = xw < g.nwx;
+        // the window's own statistics are re-read every pass (cache hits) rather than
+        // held in registers across the accumulation
+        const double s1l = wvalid ? (double)wsum_l[srow + xw] : 0.0;   // sum of (L - 128) over the window
+        const double invl = wvalid ? winv_l[srow + xw] : NAN;          // 1 / sqrt(A_L)
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             const int k = k0 + d;
@@ -402,8 +406,8 @@ __device__ __forceinline__ void finish_pass(const BandGeom &g, const float2v (&a
             if (valid) {
                 const double s1r = (double)wsum_r[srow + xr];
                 const float cross = (x & 1) ? acc[x / 2][d].y : acc[x / 2][d].x;
-                const double num = fma(n, (double)cross, -(st.s1l[x] * s1r));
-                s = num * st.invl[x] * winv_r[srow + xr];
+                const double num = fma(n, (double)cross, -(s1l * s1r));
+                s = num * invl * winv_r[srow + xr];
             }
             if (scores && wvalid && kvalid)
                 scores[((int64_t)wy * g.nwx + xw) * g.nd + k] = s;
@@ -501,11 +505,6 @@ band_scan_kernel(BandGeom g, const uint8_t *__restrict__ left, const uint8_t *__
     LaneState st;
 #pragma unroll
     for (int x = 0; x < BAND_X; ++x) {
-        const int xw = xbase + x;
-        const bool ok = active && xw < g.nwx;
-        const int64_t si = (int64_t)wy * g.stride_y * g.nsx + xw;
-        st.s1l[x] = ok ? (double)wsum_l[si] : 0.0;
-        st.invl[x] = ok ? winv_l[si] : NAN;
         st.best[x] = g.mode == SVAMD_BAND_ARGMAX ? -INFINITY : 0.0;
         st.arg[x] = g.mode == SVAMD_BAND_ARGMAX ? SVAMD_BAND_NO_MATCH : 0;
     }
@@ -522,7 +521,7 @@ band_scan_kernel(BandGeom g, const uint8_t *__restrict__ left, const uint8_t *__
             float2v acc[BAND_X / 2][1] = {};
             accumulate_rows<WIN_W, 1, true>(lp, Rt + lrow * g.lpitch + BAND_X * lane, g.lpitch, g.lpitch,
                                             g.win_h, g.win_w, acc);
-            finish_pass<1>(g, acc, g.max_disp, g.nd, true, wy, xbase, wsum_r, winv_r, st, nullptr);
+            finish_pass<1>(g, acc, g.max_disp, g.nd, true, wy, xbase, wsum_l, winv_l, wsum_r, winv_r, st, nullptr);
         }
     }
 
@@ -538,14 +537,14 @@ band_scan_kernel(BandGeom g, const uint8_t *__restrict__ left, const uint8_t *__
         for (; k + BAND_D <= kend; k += BAND_D) {
             float2v acc[BAND_X / 2][BAND_D] = {};
             accumulate_rows<WIN_W, BAND_D, true>(lp, rp + (k - k0), g.lpitch, g.rpitch, g.win_h, g.win_w, acc);
-            finish_pass<BAND_D>(g, acc, k, kend, false, wy, xbase, wsum_r, winv_r, st, SV_SCORES_OUT);
+            finish_pass<BAND_D>(g, acc, k, kend, false, wy, xbase, wsum_l, winv_l, wsum_r, winv_r, st, SV_SCORES_OUT);
             keep_pace(progress, wave, ++passes);
             SV_STAMP(1 + k / BAND_D);
         }
         for (; k < kend; ++k) {  // fewer than 8 offsets left in this chunk
             float2v acc[BAND_X / 2][1] = {};
             accumulate_rows<WIN_W, 1, false>(lp, rp + (k - k0), g.lpitch, g.rpitch, g.win_h, g.win_w, acc);
-            finish_pass<1>(g, acc, k, kend, false, wy, xbase, wsum_r, winv_r, st, SV_SCORES_OUT);
+            finish_pass<1>(g, acc, k, kend, false, wy, xbase, wsum_l, winv_l, wsum_r, winv_r, st, SV_SCORES_OUT);
         }
     }
 
