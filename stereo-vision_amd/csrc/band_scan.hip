@@ -388,6 +388,17 @@ __device__ __forceinline__ void finish_pass(const BandGeom &g, const float2v (&a
 {
     const double n = (double)(g.win_w * g.win_h);
     const int64_t srow = (int64_t)wy * g.stride_y * g.nsx;
+    // window x at offset d looks at the right-image box xbase + x + d + k0 - max_disp:
+    // BAND_X + D - 1 distinct boxes serve the lane's BAND_X * D evaluations
+    constexpr int NJ = BAND_X + D - 1;
+    double r_sum[NJ], r_inv[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int xr = xbase + j + k0 - g.max_disp;
+        const bool in = xr >= 0 && xr < g.nsx;
+        r_sum[j] = in ? (double)wsum_r[srow + xr] : 0.0;
+        r_inv[j] = in ? winv_r[srow + xr] : NAN;       // outside the image: no score
+    }
 #pragma unroll
     for (int x = 0; x < BAND_X; ++x) {
         const int xw = xbase + x;
@@ -399,15 +410,12 @@ __device__ __forceinline__ void finish_pass(const BandGeom &g, const float2v (&a
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             const int k = k0 + d;
-            const int xr = xw + k - g.max_disp;
             const bool kvalid = k < kend;
-            const bool valid = wvalid && kvalid && xr >= 0 && xr < g.nsx;
             double s = NAN;
-            if (valid) {
-                const double s1r = (double)wsum_r[srow + xr];
+            if (wvalid && kvalid) {
                 const float cross = (x & 1) ? acc[x / 2][d].y : acc[x / 2][d].x;
-                const double num = fma(n, (double)cross, -(s1l * s1r));
-                s = num * invl * winv_r[srow + xr];
+                const double num = fma(n, (double)cross, -(s1l * r_sum[x + d]));
+                s = num * invl * r_inv[x + d];
             }
             if (scores && wvalid && kvalid)
                 scores[((int64_t)wy * g.nwx + xw) * g.nd + k] = s;
