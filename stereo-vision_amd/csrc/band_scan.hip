@@ -217,29 +217,37 @@ __device__ __forceinline__ void accumulate(const float *__restrict__ lp, const f
     constexpr int NCR = (NU + D - 1 + 3) / 4;
     constexpr int AHEAD = (D + 2) / 4;
     constexpr int HEAD = AHEAD == 0 ? 1 : AHEAD;   // right quads needed before the first FMA
-    Quad l_head = load_quad<true>(lp);
-    Quad r_head[HEAD];
+    // Two sets of row registers (A, B) take turns, two rows per loop iteration: while
+    // one row is processed from set A, the first reads of the next row land in set B,
+    // and no register has to be copied.  The last row re-reads its own head (no read
+    // past the tile).
+    Quad lA = load_quad<true>(lp), lB;
+    Quad rqA[NCR], rqB[NCR];
 #pragma unroll
     for (int c = 0; c < HEAD; ++c)
-        r_head[c] = load_quad<ALIGNED>(rp + 4 * c);
+        rqA[c] = load_quad<ALIGNED>(rp + 4 * c);
+    int a = 0;
 #pragma unroll 1
-    for (int a = 0; a < rows; ++a) {
-        Quad rq[NCR];
+    for (; a + 2 <= rows; a += 2) {
+        lB = load_quad<true>(lp + lpitch);
 #pragma unroll
         for (int c = 0; c < HEAD; ++c)
-            rq[c] = r_head[c];
-        const Quad l_cur = l_head;
-        // next row's head (the last iteration re-reads its own row: no read past the tile)
-        const float *lnext = a + 1 < rows ? lp + lpitch : lp;
-        const float *rnext = a + 1 < rows ? rp + rpitch : rp;
-        l_head = load_quad<true>(lnext);
+            rqB[c] = load_quad<ALIGNED>(rp + rpitch + 4 * c);
+        row_step<WIN_W, D, ALIGNED>(acc, lp, rp, lA, rqA);
+        lp += lpitch;
+        rp += rpitch;
+        const float *lnext = a + 2 < rows ? lp + lpitch : lp;
+        const float *rnext = a + 2 < rows ? rp + rpitch : rp;
+        lA = load_quad<true>(lnext);
 #pragma unroll
         for (int c = 0; c < HEAD; ++c)
-            r_head[c] = load_quad<ALIGNED>(rnext + 4 * c);
-        row_step<WIN_W, D, ALIGNED>(acc, lp, rp, l_cur, rq);
+            rqA[c] = load_quad<ALIGNED>(rnext + 4 * c);
+        row_step<WIN_W, D, ALIGNED>(acc, lp, rp, lB, rqB);
         lp = lnext;
         rp = rnext;
     }
+    if (a < rows)
+        row_step<WIN_W, D, ALIGNED>(acc, lp, rp, lA, rqA);
 }
 
 // acc.x += l.x * r; acc.y += l.y * r with r = half RH of rpair: the left operand
