@@ -195,6 +195,9 @@ __device__ __forceinline__ void row_step(float2v (&acc)[BAND_X / 2][D], const fl
         if constexpr (C + AHEAD < NCR && C + AHEAD >= AHEAD + (AHEAD == 0 ? 1 : 0))
             rq[C + AHEAD] = load_quad<ALIGNED>(rp + 4 * (C + AHEAD));
         quad_step<WIN_W, D, C>(acc, lq, rq);
+        // keeps the scheduler from hoisting the LDS reads of later groups over this one:
+        // with them in flight early the row needs more registers than there are (spills)
+        __builtin_amdgcn_sched_barrier(0);
         row_step<WIN_W, D, ALIGNED, C + 1>(acc, lp, rp, l_head, rq);
     }
 }
