@@ -532,8 +532,11 @@ band_scan_kernel(BandGeom g, const uint8_t *__restrict__ left, const uint8_t *__
     stage_tile(left, g.H, g.W, y0, g.tile_rows, x0, g.lpitch, Lt);
     const float *lp = Lt + lrow * g.lpitch + BAND_X * lane;
 
-    if (g.mode == SVAMD_BAND_FOLD) {
-        // the centre offset is judged first: stage the right image at d = 0
+    // The centre offset is judged first (selection-rule mode).  When the whole offset
+    // range sits in LDS at once it is read from there, otherwise the right image is
+    // staged at d = 0 for it.
+    const bool whole_band = g.dchunk >= g.nd;
+    if (g.mode == SVAMD_BAND_FOLD && !whole_band) {
         stage_tile(right, g.H, g.W, y0, g.tile_rows, x0, g.lpitch, Rt);
         __syncthreads();
         if (active) {
@@ -552,6 +555,14 @@ band_scan_kernel(BandGeom g, const uint8_t *__restrict__ left, const uint8_t *__
         if (!active)
             continue;
         const float *rp = Rt + lrow * g.rpitch + BAND_X * lane;
+        if (g.mode == SVAMD_BAND_FOLD && whole_band) {
+            float2v acc[BAND_X / 2][1] = {};
+            if (g.max_disp & 3)
+                accumulate_rows<WIN_W, 1, false>(lp, rp + g.max_disp, g.lpitch, g.rpitch, g.win_h, g.win_w, acc);
+            else
+                accumulate_rows<WIN_W, 1, true>(lp, rp + g.max_disp, g.lpitch, g.rpitch, g.win_h, g.win_w, acc);
+            finish_pass<1>(g, acc, g.max_disp, g.nd, true, wy, xbase, wsum_l, winv_l, wsum_r, winv_r, st, nullptr);
+        }
         int k = k0;
         for (; k + BAND_D <= kend; k += BAND_D) {
             float2v acc[BAND_X / 2][BAND_D] = {};
