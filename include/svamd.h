@@ -5,7 +5,7 @@
  * The reference is pure Python and has no FFI of its own; each entry point
  * below replaces the Python function cited beside it (paths relative to the
  * reference checkout) and is what a ctypes binding in that function's module
- * would call.  The binding stubs are shown in INTEGRATION.md.
+ * would call.
  *
  * Conventions
  *  - Every array argument is a DEVICE pointer (hipMalloc'd or a torch tensor's
