@@ -9,8 +9,10 @@ One process per GPU (torch.distributed over RCCL when N > 1).  Every rank scans
 its own pair per step (weak scaling: the job is a batch of N pairs, i.e. row
 bands of an N-times taller strip); only the per-window results (int16 disparity
 + float32 correlation) are gathered to rank 0.  A step = summed-area tables +
-window statistics (K1) + the band kernel (K2) + the gather.  Rank 0 prints one
-JSON line.
+window statistics (K1) + the band kernel (K2) + the gather; the gather of step i
+is issued asynchronously and travels while step i + 1 computes (two result
+buffers take turns), every gather has completed before the clock stops.  Rank 0
+prints one JSON line.
 
 metric: NCC window evaluations per second, an evaluation being one (window,
 offset) score = 2 * 31 * 31 algorithmic float32 flops of cross term.
@@ -136,13 +138,17 @@ def main():
     # results travel as one byte buffer per rank: int16 disparities then float32
     # correlations (6 bytes per window; 16-bit integers are not a collective dtype)
     nwin = scanner.disp.numel()
-    packed = torch.empty(6 * nwin, dtype=torch.uint8, device='cuda')
-    disp16 = packed[:2 * nwin].view(torch.int16).view(scanner.disp.shape)
-    val32 = packed[2 * nwin:].view(torch.float32).view(scanner.val.shape)
     wire = 'cuda' if backend == 'nccl' else 'cpu'
-    gathered = None
-    if world > 1 and rank == 0:
-        gathered = [torch.empty(6 * nwin, dtype=torch.uint8, device=wire) for _ in range(world)]
+    packed, disp16, val32, gathered = [], [], [], []
+    for _ in range(2 if world > 1 else 0):          # two buffers take turns
+        buf = torch.empty(6 * nwin, dtype=torch.uint8, device='cuda')
+        packed.append(buf)
+        disp16.append(buf[:2 * nwin].view(torch.int16).view(scanner.disp.shape))
+        val32.append(buf[2 * nwin:].view(torch.float32).view(scanner.val.shape))
+        gathered.append([torch.empty(6 * nwin, dtype=torch.uint8, device=wire) for _ in range(world)]
+                        if rank == 0 else None)
+    in_flight = [None, None]
+    issued = [0]
 
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
@@ -155,12 +161,23 @@ def main():
         if i is not None:
             ev1[i].record()
         if world > 1:                                       # results -> rank 0 over RCCL
-            disp16.copy_(scanner.disp)
-            val32.copy_(scanner.val)
-            dist.gather(packed.to(wire), gathered, dst=0)
+            b = issued[0] % 2
+            issued[0] += 1
+            if in_flight[b] is not None:
+                in_flight[b].wait()                         # this buffer's previous gather has landed
+            disp16[b].copy_(scanner.disp)
+            val32[b].copy_(scanner.val)
+            in_flight[b] = dist.gather(packed[b].to(wire), gathered[b], dst=0, async_op=True)
+
+    def drain():
+        for b in range(2):
+            if in_flight[b] is not None:
+                in_flight[b].wait()
+                in_flight[b] = None
 
     for _ in range(args.warmup):
         step()
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -168,6 +185,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
