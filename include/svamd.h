@@ -223,6 +223,28 @@ size_t svamd_peak_mask_workspace_bytes(int H, int W);
 int svamd_peak_mask(const double *data, int H, int W, int size, double threshold, uint8_t *mask,
                     void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- image preparation ahead of the scans --------------------------------------
+ * utils.py:6-15 (and the `.convert('L')` calls of the drivers, e.g.
+ * test_image_comparison.py:36-44).  pixels: H x W x channels uint8, interleaved
+ * (1 = grey, 2 = grey + alpha, 3 = RGB, 4 = RGBA).  Grey level = PIL's "L":
+ * (19595 R + 38470 G + 7471 B + 32768) >> 16.  grey_u8 (H x W uint8) and / or
+ * grey_f64 (H x W float64) receive it; with nan_alpha != 0 the float64 output is
+ * NaN where alpha == 0 (utils.py:13-14).  Either output may be NULL, not both. */
+int svamd_greyscale(const uint8_t *pixels, int channels, int H, int W, int nan_alpha, uint8_t *grey_u8,
+                    double *grey_f64, void *stream);
+
+/* utils.py:28-35: scikit-image 0.19 `resize(image, (out_h, out_w))` with its
+ * defaults, i.e. uint8 values times 1/255 (float64 images unchanged), a Gaussian
+ * filter of sigma (in/out - 1)/2 along each axis that shrinks (radius
+ * int(4 sigma + 0.5), borders mirrored about the edge pixel), linear
+ * interpolation at (k + 0.5) in/out - 0.5, and a clip to the input's range.
+ * image: H x W of `dtype` (SVAMD_U8 or SVAMD_F64); out: out_h x out_w float64.
+ * NaNs spread to every output the filter or the interpolation draws them into,
+ * as they do in the reference.  Reduction factors up to 128. */
+size_t svamd_downsample_workspace_bytes(int H, int W);
+int svamd_downsample(const void *image, int dtype, int H, int W, int out_h, int out_w, double *out,
+                     void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -388,3 +388,111 @@ def find_peaks(region, neighborhood_size, threshold):
     x = np.array([(b[2] + b[3]) / 2 for b in boxes]) + template.shape[1] / 2
     y = np.array([(b[0] + b[1]) / 2 for b in boxes]) + template.shape[0] / 2
     return x, y
+
+
+# ---- image preparation (reference utils.py:6-15, 28-35) -------------------------------
+def greyscale(pixels, nan_alpha=False):
+    '''PIL's "L" conversion of 8-bit pixels (H x W, H x W x 2 grey + alpha, RGB or
+    RGBA): (19595 R + 38470 G + 7471 B + 32768) >> 16.  With nan_alpha the result
+    is float64 with NaN where alpha is 0 (reference utils.py:11-15), else uint8.'''
+    pixels = np.asarray(pixels)
+    if pixels.ndim == 2:
+        grey, alpha = pixels.astype(np.uint32), None
+    elif pixels.shape[2] == 2:
+        grey, alpha = pixels[..., 0].astype(np.uint32), pixels[..., 1]
+    else:
+        r, g, b = (pixels[..., c].astype(np.uint32) for c in range(3))
+        grey = (19595 * r + 38470 * g + 7471 * b + 32768) >> 16
+        alpha = pixels[..., 3] if pixels.shape[2] == 4 else None
+    if not nan_alpha:
+        return grey.astype(np.uint8)
+    out = grey.astype(np.float64)
+    if alpha is not None:
+        out[alpha == 0] = np.nan
+    return out
+
+
+def _mirror(i, n):
+    '''Index folding for borders mirrored about the edge pixel: c b | a b c | b a.'''
+    if n == 1:
+        return np.zeros_like(i)
+    p = 2 * n - 2
+    i = np.mod(i, p)
+    return np.where(i < n, i, p - i)
+
+
+def _gaussian_axis(image, sigma, axis):
+    '''scipy.ndimage.gaussian_filter1d (truncate 4, mode "mirror"): centre tap
+    first, then the tap pairs from the outermost inwards.'''
+    radius = int(4.0 * sigma + 0.5)
+    x = np.arange(-radius, radius + 1)
+    phi = np.exp(-0.5 / (sigma * sigma) * x ** 2)
+    phi = phi / phi.sum()
+    data = np.moveaxis(image, axis, 0)
+    n = data.shape[0]
+    c = np.arange(n)
+    acc = data * phi[radius]
+    for k in range(radius, 0, -1):
+        acc = acc + (data[_mirror(c - k, n)] + data[_mirror(c + k, n)]) * phi[radius - k]
+    return np.moveaxis(acc, 0, axis)
+
+
+def _zoom_axis_plan(n_in, n_out):
+    '''Source rows and weights of scipy.ndimage.zoom(order=1, mode="mirror",
+    grid_mode=True) along one axis.'''
+    zoom = n_in / n_out
+    cc = (np.arange(n_out) + 0.5) * zoom - 0.5
+    if n_in > 1:
+        sz2 = 2 * n_in - 2
+        neg = cc < 0
+        folded = sz2 * np.trunc(-cc / sz2) + cc
+        folded = np.where(folded <= 1 - n_in, folded + sz2, -folded)
+        over = cc > n_in - 1
+        wrapped = cc - sz2 * np.trunc(cc / sz2)
+        wrapped = np.where(wrapped > n_in - 1, sz2 - wrapped, wrapped)
+        cc = np.where(neg, folded, np.where(over, wrapped, cc))
+    else:
+        cc = np.zeros(n_out)
+    start = np.floor(cc)
+    w0 = 1.0 - (cc - start)
+    w1 = 1.0 - w0
+    start = start.astype(np.int64)
+    return _mirror(start, n_in), _mirror(start + 1, n_in), w0, w1
+
+
+def resize(image, out_shape):
+    '''scikit-image 0.19 `resize(image, out_shape)` with its defaults, for 2D uint8
+    or float64 images: scaling of integer values by 1 / 255, Gaussian anti-aliasing
+    of sigma (in / out - 1) / 2 per shrinking axis, linear interpolation on the
+    pixel-area grid, clip to the scaled input's range (NaNs ignored).'''
+    image = np.asarray(image)
+    if image.dtype == np.uint8:
+        image = image * (1.0 / 255)
+    else:
+        image = image.astype(np.float64)
+    h, w = image.shape
+    oh, ow = out_shape
+    filtered = image
+    if oh < h or ow < w:
+        for axis, (n_in, n_out) in enumerate(((h, oh), (w, ow))):
+            sigma = max(0.0, (n_in / n_out - 1) / 2)
+            if sigma > 1e-15:
+                filtered = _gaussian_axis(filtered, sigma, axis)
+    y0, y1, wy0, wy1 = _zoom_axis_plan(h, oh)
+    x0, x1, wx0, wx1 = _zoom_axis_plan(w, ow)
+    wy0, wy1 = wy0[:, None], wy1[:, None]
+    out = np.zeros((oh, ow))
+    out = out + filtered[np.ix_(y0, x0)] * wy0 * wx0
+    out = out + filtered[np.ix_(y0, x1)] * wy0 * wx1
+    out = out + filtered[np.ix_(y1, x0)] * wy1 * wx0
+    out = out + filtered[np.ix_(y1, x1)] * wy1 * wx1
+    if not np.all(np.isnan(image)):
+        lo, hi = np.nanmin(image), np.nanmax(image)
+        out = np.where(out < lo, lo, np.where(out > hi, hi, out))
+    return out
+
+
+def downsample(image, factor=1):
+    '''reference utils.py:28-35.'''
+    image = np.asarray(image)
+    return resize(image, (math.floor(image.shape[0] / factor), math.floor(image.shape[1] / factor)))

@@ -342,7 +342,54 @@ def config_audio():
          scale=float(np.max(np.abs(ref))))
 
 
+def config_prepare():
+    '''Image preparation on the device: RGBA -> grey with NaN transparency and a
+    factor-2 downsample of a 4096x4096 image; device time between events and the
+    bytes each step must move (input read once, output written once).'''
+    import utils
+    from scipy import ndimage
+    rng = np.random.default_rng(11)
+    h = w = 4096
+    rgba = rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8)
+    d_rgba = nv.to_device(rgba)
+    grey = nv.empty((h, w), torch.float64)
+    grey8 = nv.empty((h, w), torch.uint8)
+    out = nv.empty((h // 2, w // 2), torch.float64)
+    nbytes = nv.load_library().svamd_downsample_workspace_bytes(h, w)
+    ws = nv.workspace(nbytes)
+
+    def device_ms(fn, repeat=10):
+        fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(repeat):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / repeat
+
+    ms = device_ms(lambda: nv.call('svamd_greyscale', nv.ptr(d_rgba), 4, h, w, 1, nv.ptr(grey8), nv.ptr(grey),
+                                   nv.stream_ptr()))
+    moved = h * w * (4 + 1 + 8)
+    emit(config='N3', what='greyscale with NaN transparency, 4096x4096 RGBA -> uint8 + float64 (device)',
+         ms=ms, gbytes_per_s=moved / ms / 1e6, fraction_of_hbm_peak=moved / ms / 1e6 / 8000)
+    for code, src, label in ((nv.U8, grey8, 'uint8'), (nv.F64, grey, 'float64')):
+        ms = device_ms(lambda: nv.call('svamd_downsample', nv.ptr(src), code, h, w, h // 2, w // 2, nv.ptr(out),
+                                       nv.ptr(ws), nbytes, nv.stream_ptr()))
+        moved = h * w * (1 if code == nv.U8 else 8) + (h // 2) * (w // 2) * 8
+        emit(config='N3', what=f'downsample by 2, 4096x4096 {label} -> 2048x2048 float64 (device, 4 kernels)',
+             ms=ms, algorithmic_gbytes_per_s=moved / ms / 1e6)
+    host = grey8.cpu().numpy()
+    dt, _ = timed(utils.downsample, host, 2)
+    emit(config='N3', what='downsample(image, 2) call on a host uint8 4096x4096 image (incl. transfers)', seconds=dt)
+    t0 = time.perf_counter()
+    img = host * (1.0 / 255)
+    ndimage.zoom(ndimage.gaussian_filter(img, 0.5, mode='mirror'), 0.5, order=1, mode='mirror', grid_mode=True)
+    emit(config='N3', what='cpu scipy.ndimage route of the same image (what scikit-image resize runs, 1 thread)',
+         seconds=time.perf_counter() - t0)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['1', '1d', '2', '3', '4b', '5', 'n1', 'n2', 'n4']
+    which = sys.argv[1:] or ['1', '1d', '2', '3', '4b', '5', 'n1', 'n2', 'n3', 'n4']
     for c in which:
-        {'1': config1, '1d': config1_device, '2': config2, 'n1': config_grids, 'n2': config_peaks, 'n4': config_audio, '3': config3, '4b': config4b, '5': config5}[c]()
+        {'1': config1, '1d': config1_device, '2': config2, 'n1': config_grids, 'n2': config_peaks, 'n3': config_prepare, 'n4': config_audio, '3': config3, '4b': config4b, '5': config5}[c]()

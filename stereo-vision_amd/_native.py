@@ -59,6 +59,9 @@ PROTOTYPES = {
     'svamd_grid_average': (_i, [_vp, _vp, _vp, _vp, _i64, _vp]),
     'svamd_peak_mask_workspace_bytes': (_sz, [_i, _i]),
     'svamd_peak_mask': (_i, [_vp, _i, _i, _i, _d, _vp, _vp, _sz, _vp]),
+    'svamd_greyscale': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    'svamd_downsample_workspace_bytes': (_sz, [_i, _i]),
+    'svamd_downsample': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
 }
 
 _lib = None

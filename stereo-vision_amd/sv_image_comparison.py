@@ -12,7 +12,7 @@ import numpy as np
 
 import correlation_spectral
 from correlation_spectral import cross_correlate_2d_spectral as x_corr_2d
-from utils import max_pos
+from utils import max_pos, resident_float64
 import _native as nv
 import sharding
 
@@ -426,8 +426,8 @@ def sequence_scan(left_image, right_image, scan_config):
     def resident():
         nonlocal left_dev, right_dev
         if left_dev is None:
-            left_dev = nv.to_device(np.ascontiguousarray(left_image, dtype=np.float64))
-            right_dev = nv.to_device(np.ascontiguousarray(right_image, dtype=np.float64))
+            left_dev = resident_float64(left_image)
+            right_dev = resident_float64(right_image)
         return left_dev, right_dev
 
     for stage, stage_config in enumerate(scan_config):

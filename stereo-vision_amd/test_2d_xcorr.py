@@ -6,11 +6,10 @@ from argparse import ArgumentParser
 from datetime import datetime
 
 import numpy as np
-from PIL import Image
 
 from correlation import cross_correlate_2d
 from correlation_spectral import cross_correlate_2d_spectral
-from utils import greyscale_with_nan, max_pos
+from utils import greyscale, greyscale_with_nan, max_pos
 
 
 def main():
@@ -23,10 +22,10 @@ def main():
     parser.add_argument('--no_plot', action='store_true', default=False)
     args = parser.parse_args()
 
-    region = np.asarray(Image.open(f'{args.images_dir}/{args.region}').convert('L'))
+    region = greyscale(f'{args.images_dir}/{args.region}')
     start = datetime.now()
     if args.spectral:
-        template = np.asarray(Image.open(f'{args.images_dir}/{args.template}').convert('L'))
+        template = greyscale(f'{args.images_dir}/{args.template}')
         step = 1
         region_cor = cross_correlate_2d_spectral(template, region)
     else:

@@ -9,11 +9,10 @@ from argparse import ArgumentParser
 from datetime import datetime
 
 import numpy as np
-from PIL import Image
 
 from depth_grids import DepthGrids
 from sv_image_comparison import sequence_scan, plot_sequence_output
-from utils import downsample
+from utils import downsample, greyscale
 
 
 def calc_max_shift_magnitude(config):
@@ -45,7 +44,7 @@ def main():
     if args.depth_input is None:
         images = []
         for side in ('left', 'right'):
-            image = np.asarray(Image.open(f'{args.image_dir}/{side}_{args.images}.tiff').convert('L'))
+            image = greyscale(f'{args.image_dir}/{side}_{args.images}.tiff')
             images.append(downsample(image, args.ds_factor))
         left_image, right_image = images
         totals = DepthGrids(left_image.shape)

@@ -416,6 +416,20 @@ def g11_find_peaks(ref):
     save('g11_find_peaks', **arrays)
 
 
+def g12_greyscale_with_nan(ref):
+    '''The reference's loader on its two RGBA images: decoded pixels in, grey
+    levels with NaN for transparent pixels out.'''
+    from PIL import Image
+    utils = ref[3]
+    arrays = {}
+    for key, name in (('template', 'template.PNG'), ('rm_template', 'rm_template.png')):
+        path = f'{REF}/images/{name}'
+        arrays[f'{key}_rgba'] = np.asarray(Image.open(path))
+        arrays[f'{key}_grey'] = utils.greyscale_with_nan(path)
+        print(f'  g12 {name}: {arrays[f"{key}_rgba"].shape}, NaNs {np.isnan(arrays[f"{key}_grey"]).sum()}')
+    save('g12_greyscale_with_nan', **arrays)
+
+
 GROUPS = {
     'g1': g1_spatial_template_region,
     'g2': g2_spatial_nan_template,
@@ -428,6 +442,7 @@ GROUPS = {
     'g9': g9_multipass,
     'g10': g10_depth_grids,
     'g11': g11_find_peaks,
+    'g12': g12_greyscale_with_nan,
 }
 
 

@@ -190,3 +190,72 @@ def test_g11_find_peaks(oracle, tag):
     g = golden('g11_find_peaks')
     x, y = oracle.find_peaks(g[f'{tag}_image'], 10, 0.2)
     assert np.array_equal(x, g[f'{tag}_x']) and np.array_equal(y, g[f'{tag}_y'])
+
+
+# ---- image preparation ---------------------------------------------------------------
+def test_g12_greyscale_with_nan(oracle):
+    '''The reference's loader on its own two RGBA images: same grey levels, NaN at
+    the same pixels, bit for bit.'''
+    g = golden('g12_greyscale_with_nan')
+    for key in ('template', 'rm_template'):
+        got = oracle.greyscale(g[f'{key}_rgba'], nan_alpha=True)
+        assert np.array_equal(got, g[f'{key}_grey'], equal_nan=True)
+    # the spatial golden's template is the same loader's output
+    assert np.array_equal(oracle.greyscale(g['rm_template_rgba'], nan_alpha=True),
+                          golden('g2_spatial_nan_template')['template'], equal_nan=True)
+
+
+@pytest.mark.parametrize('mode,channels', [('RGBA', 4), ('RGB', 3), ('LA', 2), ('L', 1)])
+def test_greyscale_matches_pil(oracle, mode, channels):
+    from PIL import Image
+    rng = np.random.default_rng(channels)
+    pixels = rng.integers(0, 256, size=(37, 41, channels), dtype=np.uint8)
+    if channels == 1:
+        pixels = pixels[..., 0]
+    ref = np.asarray(Image.fromarray(pixels, mode=mode).convert('L'))
+    assert np.array_equal(oracle.greyscale(pixels), ref)
+
+
+def ndimage_resize(image, out_shape):
+    '''The scipy.ndimage calls scikit-image 0.19's `resize` makes with its defaults
+    (scikit-image itself is not installed: parity with it is unpinned, parity with
+    the library it delegates to is what this checks).'''
+    from scipy import ndimage
+    image = np.asarray(image)
+    if image.dtype == np.uint8:
+        image = np.multiply(image, 1. / 255, dtype=np.float64)
+    factors = np.divide(image.shape, out_shape)
+    filtered = image
+    if any(o < i for o, i in zip(out_shape, image.shape)):
+        filtered = ndimage.gaussian_filter(image, np.maximum(0, (factors - 1) / 2), cval=0, mode='mirror')
+    out = ndimage.zoom(filtered, [1 / f for f in factors], order=1, mode='mirror', cval=0, grid_mode=True)
+    np.clip(out, np.nanmin(image), np.nanmax(image), out=out)
+    return out
+
+
+RESIZE_CASES = [((64, 80), 2, 'u8'), ((101, 77), 3, 'u8'), ((50, 64), 1, 'u8'), ((40, 200), 4, 'f64'),
+                ((33, 47), 1.5, 'f64'), ((50, 300), 7, 'u8'), ((64, 64), 2, 'nan'), ((9, 2000), 1, 'f64'),
+                ((1, 64), 2, 'f64'), ((30, 30), 0.5, 'f64')]
+
+
+def resize_case(shape, factor, kind):
+    rng = np.random.default_rng(shape[0] * 1000 + shape[1])
+    if kind == 'u8':
+        image = rng.integers(0, 256, size=shape, dtype=np.uint8)
+    else:
+        image = rng.normal(size=shape) * 50
+        if kind == 'nan':
+            image[10:12, 20:23] = np.nan
+    return image, (max(1, int(np.floor(shape[0] / factor))), int(np.floor(shape[1] / factor)))
+
+
+@pytest.mark.parametrize('shape,factor,kind', RESIZE_CASES)
+def test_resize_matches_ndimage(oracle, shape, factor, kind):
+    image, out_shape = resize_case(shape, factor, kind)
+    got, ref = oracle.resize(image, out_shape), ndimage_resize(image, out_shape)
+    if factor >= 1:
+        assert np.array_equal(got, ref, equal_nan=True)      # same operations in the same order
+    else:
+        close(got, ref, 1e-13)
+    if shape[0] > 1:
+        assert np.array_equal(oracle.downsample(image, factor), got, equal_nan=True)

@@ -613,6 +613,96 @@ def test_peak_mask_vs_oracle_and_scipy(mods, oracle, shape, size, thr):
     assert np.array_equal(got, (data == dmax) & ((dmax - dmin) > thr))
 
 
+# ---- image preparation ---------------------------------------------------------------------
+def test_g12_greyscale_with_nan(mods, tmp_path):
+    '''The reference's loader on its own RGBA images: identical grey levels and
+    NaN pixels, from the file as well as from decoded pixels.'''
+    from PIL import Image
+    g = golden('g12_greyscale_with_nan')
+    for key in ('template', 'rm_template'):
+        rgba = g[f'{key}_rgba']
+        dev = mods['u']._greyscale_on_device(rgba, nan_alpha=True, want_u8=False)
+        assert np.array_equal(dev.cpu().numpy(), g[f'{key}_grey'], equal_nan=True)
+        Image.fromarray(rgba, 'RGBA').save(tmp_path / f'{key}.png')
+        image = mods['u'].greyscale_with_nan(str(tmp_path / f'{key}.png'))
+        assert isinstance(image, np.ndarray) and image.dtype == np.float64
+        assert np.array_equal(image, g[f'{key}_grey'], equal_nan=True)
+        assert np.array_equal(image.resident.cpu().numpy(), g[f'{key}_grey'], equal_nan=True)
+    Image.fromarray(g['template_rgba'][..., :3].copy(), 'RGB').save(tmp_path / 'rgb.png')
+    with pytest.raises(ValueError):
+        mods['u'].greyscale_with_nan(str(tmp_path / 'rgb.png'))
+
+
+@pytest.mark.parametrize('mode,channels', [('RGBA', 4), ('RGB', 3), ('LA', 2), ('L', 1)])
+def test_greyscale_modes(mods, oracle, tmp_path, mode, channels):
+    from PIL import Image
+    rng = np.random.default_rng(channels)
+    pixels = rng.integers(0, 256, size=(203, 331, channels), dtype=np.uint8)
+    if channels == 1:
+        pixels = pixels[..., 0]
+    Image.fromarray(pixels, mode=mode).save(tmp_path / 'image.png')
+    got = mods['u'].greyscale(str(tmp_path / 'image.png'))
+    assert got.dtype == np.uint8
+    assert np.array_equal(got, oracle.greyscale(pixels))
+    assert np.array_equal(got, np.asarray(Image.open(tmp_path / 'image.png').convert('L')))
+
+
+RESIZE_TOL = 1e-12   # float64; the Gaussian weights come from two different exp()s
+
+
+@pytest.mark.parametrize('shape,factor,kind', [
+    ((64, 80), 2, 'u8'), ((101, 77), 3, 'u8'), ((50, 64), 1, 'u8'), ((40, 200), 4, 'f64'), ((33, 47), 1.5, 'f64'),
+    ((50, 300), 7, 'u8'), ((64, 64), 2, 'nan'), ((9, 2000), 1, 'f64'), ((30, 30), 0.5, 'f64'),
+    ((1000, 1500), 2, 'u8'), ((700, 900), 5, 'nan'), ((4, 700), 3, 'u8')])
+def test_downsample_vs_oracle(mods, oracle, shape, factor, kind):
+    rng = np.random.default_rng(shape[0] * 1000 + shape[1])
+    if kind == 'u8':
+        image = rng.integers(0, 256, size=shape, dtype=np.uint8)
+    else:
+        image = rng.normal(size=shape) * 50
+        if kind == 'nan':
+            image[10:12, 20:23] = np.nan
+    got = mods['u'].downsample(image, factor)
+    want = oracle.downsample(image, factor)
+    assert got.shape == want.shape and got.dtype == np.float64
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    if factor == 1:
+        assert np.array_equal(got, want, equal_nan=True)        # no filter: the same four products
+    else:
+        m = ~np.isnan(want)
+        scale = np.nanmax(np.abs(want))
+        assert np.max(np.abs(got[m] - want[m])) <= RESIZE_TOL * scale
+    assert np.array_equal(got.resident.cpu().numpy(), np.asarray(got), equal_nan=True)
+
+
+def test_downsample_rejects(mods):
+    with pytest.raises(TypeError):
+        mods['u'].downsample(np.zeros((8, 8), np.int32), 2)
+    with pytest.raises(ValueError):
+        mods['u'].downsample(np.zeros((8, 8, 3), np.uint8), 2)
+    with pytest.raises(mods['n'].NativeError):
+        mods['u'].downsample(np.zeros((600, 8)), 300)
+
+
+def test_resident_images_feed_the_scan(mods):
+    '''Images that come out of the device preparation are scanned from their
+    device copies; the results are those of the same values uploaded afresh.'''
+    g = golden('g6_cone_images')
+    cfg = [{'window_width': 40, 'window_height': 40, 'scheme': [5, 1], 'scheme_shift_size': [10, 10],
+            'window_overlap': 0.5, 'correlation_threshold': 0.6}, {'factor': 2}]
+    left, right = (mods['u'].downsample(np.ascontiguousarray(g[k]), 2) for k in ('left', 'right'))
+    assert left.resident is not None and left[::2].resident is None
+    with pytest.raises(ValueError):
+        left[0, 0] = 1.0
+    a = quiet(mods['v'].sequence_scan, left, right, cfg)
+    b = quiet(mods['v'].sequence_scan, np.array(left), np.array(right), cfg)
+    assert len(a) == len(b) == 2
+    for sa, sb in zip(a, b):
+        assert list(sa) == list(sb)
+        for wid in sa:
+            assert (sa[wid]['dp_x'], sa[wid]['dp_y']) == (sb[wid]['dp_x'], sb[wid]['dp_y'])
+
+
 # ---- driver scripts --------------------------------------------------------------------
 def run_driver(module, argv, monkeypatch, capsys):
     import importlib
