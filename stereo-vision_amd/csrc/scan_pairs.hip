@@ -257,18 +257,27 @@ __device__ __forceinline__ void pk_fma_tb(pf2 &acc, const pf2 &tpair, const pf2 
         asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(tpair), "v"(w));
 }
 
-struct ColQuad {           // four consecutive columns of a row pair
-    pf2 c[4];
+struct ColQuad {           // four consecutive columns of a row pair, as the two 16-byte reads left them
+    pf4 lo, hi;
+    template <int C> __device__ __forceinline__ pf2 col() const
+    {
+        if constexpr (C == 0)
+            return lo.xy;
+        else if constexpr (C == 1)
+            return lo.zw;
+        else if constexpr (C == 2)
+            return hi.xy;
+        else
+            return hi.zw;
+    }
 };
 
-__device__ __forceinline__ ColQuad load_colquad(const float *p)
+// sw (0 or 4): the row's 16-byte slots are stored swapped in pairs (see pair_row_swap)
+__device__ __forceinline__ ColQuad load_colquad(const float *p, int sw)
 {
-    const pf4 lo = *reinterpret_cast<const pf4 *>(p), hi = *reinterpret_cast<const pf4 *>(p + 4);
     ColQuad q;
-    q.c[0] = lo.xy;
-    q.c[1] = lo.zw;
-    q.c[2] = hi.xy;
-    q.c[3] = hi.zw;
+    q.lo = *reinterpret_cast<const pf4 *>(p + sw);
+    q.hi = *reinterpret_cast<const pf4 *>(p + (4 ^ sw));
     return q;
 }
 
@@ -281,7 +290,7 @@ __device__ __forceinline__ void pair_group(pf2 (&acc)[G], const pf4 &t, const Co
             constexpr int C = I + J;
             const ColQuad &q = C < 4 ? q0 : (C < 8 ? q1 : q2);
             const pf2 tp = (I & 2) ? pf2(t.zw) : pf2(t.xy);
-            pk_fma_tb<(I & 1)>(acc[J], tp, q.c[C & 3]);
+            pk_fma_tb<(I & 1)>(acc[J], tp, q.template col<(C & 3)>());
             pair_group<G, I, J + 1>(acc, t, q0, q1, q2);
         } else {
             pair_group<G, I + 1, 0>(acc, t, q0, q1, q2);
@@ -293,11 +302,11 @@ __device__ __forceinline__ void pair_group(pf2 (&acc)[G], const pf4 &t, const Co
 // starting at the task's first column.
 template <int G>
 __device__ __forceinline__ void pair_row(pf2 (&acc)[G], const float *__restrict__ trow,
-                                         const float *__restrict__ srow, int groups)
+                                         const float *__restrict__ srow, int sw, int groups)
 {
     // the window's quads rotate through q0, q1, q2 (q0, q1 for G = 4); whole rotations
     // in the loop, so that every register is back in its role at the loop's end
-    ColQuad q0 = load_colquad(srow), q1, q2;
+    ColQuad q0 = load_colquad(srow, sw), q1, q2;
     const pf4 *t4 = reinterpret_cast<const pf4 *>(trow);
     int g = 0;
     if constexpr (G == 8) {
@@ -305,65 +314,92 @@ __device__ __forceinline__ void pair_row(pf2 (&acc)[G], const float *__restrict_
         // requested before the current group's FMAs, so one wavefront alone hides the
         // LDS latency
         ColQuad q3;
-        q1 = load_colquad(srow + 8);
-        q2 = load_colquad(srow + 16);
+        q1 = load_colquad(srow + 8, sw);
+        q2 = load_colquad(srow + 16, sw);
         pf4 ta = t4[0], tb;
         for (; g + 4 <= groups; g += 4) {
-            q3 = load_colquad(srow + 8 * (g + 3));
+            q3 = load_colquad(srow + 8 * (g + 3), sw);
             tb = t4[g + 1];
             pair_group<G>(acc, ta, q0, q1, q2);
-            q0 = load_colquad(srow + 8 * (g + 4));
+            __builtin_amdgcn_sched_barrier(0);
+            q0 = load_colquad(srow + 8 * (g + 4), sw);
             ta = t4[g + 2];
             pair_group<G>(acc, tb, q1, q2, q3);
-            q1 = load_colquad(srow + 8 * (g + 5));
+            __builtin_amdgcn_sched_barrier(0);
+            q1 = load_colquad(srow + 8 * (g + 5), sw);
             tb = t4[g + 3];
             pair_group<G>(acc, ta, q2, q3, q0);
-            q2 = load_colquad(srow + 8 * (g + 6));
+            __builtin_amdgcn_sched_barrier(0);
+            q2 = load_colquad(srow + 8 * (g + 6), sw);
             ta = t4[g + 4];
             pair_group<G>(acc, tb, q3, q0, q1);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (g < groups) {
-            q3 = load_colquad(srow + 8 * (g + 3));
+            q3 = load_colquad(srow + 8 * (g + 3), sw);
             tb = t4[g + 1];
             pair_group<G>(acc, ta, q0, q1, q2);
+            __builtin_amdgcn_sched_barrier(0);
             if (g + 1 < groups) {
-                q0 = load_colquad(srow + 8 * (g + 4));
+                q0 = load_colquad(srow + 8 * (g + 4), sw);
                 ta = t4[g + 2];
                 pair_group<G>(acc, tb, q1, q2, q3);
+            __builtin_amdgcn_sched_barrier(0);
                 if (g + 2 < groups)
                     pair_group<G>(acc, ta, q2, q3, q0);
+            __builtin_amdgcn_sched_barrier(0);
             }
         }
     } else {
         // G = 4: two quads per group, three in rotation (one requested ahead)
-        q1 = load_colquad(srow + 8);
+        q1 = load_colquad(srow + 8, sw);
         pf4 ta = t4[0], tb, tc;
         for (; g + 3 <= groups; g += 3) {
-            q2 = load_colquad(srow + 8 * (g + 2));
+            q2 = load_colquad(srow + 8 * (g + 2), sw);
             tb = t4[g + 1];
             pair_group<G>(acc, ta, q0, q1, q1);
-            q0 = load_colquad(srow + 8 * (g + 3));
+            __builtin_amdgcn_sched_barrier(0);
+            q0 = load_colquad(srow + 8 * (g + 3), sw);
             tc = t4[g + 2];
             pair_group<G>(acc, tb, q1, q2, q2);
-            q1 = load_colquad(srow + 8 * (g + 4));
+            __builtin_amdgcn_sched_barrier(0);
+            q1 = load_colquad(srow + 8 * (g + 4), sw);
             ta = t4[g + 3];
             pair_group<G>(acc, tc, q2, q0, q0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (g < groups) {
-            q2 = load_colquad(srow + 8 * (g + 2));
+            q2 = load_colquad(srow + 8 * (g + 2), sw);
             tb = t4[g + 1];
             pair_group<G>(acc, ta, q0, q1, q1);
+            __builtin_amdgcn_sched_barrier(0);
             if (g + 1 < groups)
                 pair_group<G>(acc, tb, q1, q2, q2);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
 
 // Row pitch (in columns) of the row-pair image S: the padded surface columns, the
-// padded template width and the quads the window prefetch reads ahead.
+// padded template width and the quads the window prefetch reads ahead.  2 mod 4
+// columns = 8 mod 16 banks from one row pair to the next but one (see pair_row_swap).
 __host__ __device__ __forceinline__ int pair_row_pitch(int gcols, int mwp)
 {
-    return (gcols + mwp + 12 + 3) & ~3;
+    return ((gcols + mwp + 12 + 3) & ~3) + 2;
+}
+
+// LDS banks.  A lane reads its window 16 bytes at a time and its neighbour's window
+// starts 8 G bytes further on, so the lanes of one surface row pair touch only
+// every other (G = 4) or every fourth (G = 8) group of four banks; the next lanes of
+// a 16-lane read group work on row pairs 2, 4, 6 rows further down, a multiple of 8
+// banks away, and would collide with them.  Rows whose index has bit 1 (G = 4) or
+// bit 2 (G = 8) set are therefore stored with the two 16-byte slots of every 32
+// bytes exchanged: together with the pitch this spreads a read group over all 64
+// banks.  Returns the float offset to XOR into an in-row offset (0 or 4).
+template <int G>
+__device__ __forceinline__ int pair_row_swap(int a)
+{
+    return ((a >> (G == 4 ? 1 : 2)) & 1) << 2;
 }
 
 struct SlotInfo {
@@ -489,12 +525,13 @@ scan_pairs_f32_kernel(const double *__restrict__ tbase, const double *__restrict
             if (flat)
                 continue;
             // S[a][x] = (r'[a][x mod rw], r'[(a + 1) mod rh][x mod rw]) from the plain copy
-            for (int x = lane; x < rxp; x += nthr) {
+            // (the pitch's last two columns only shift the banks and hold nothing)
+            for (int x = lane; x < rxp - 2; x += nthr) {
                 const int xs = x % rw;
                 float cur = Ps[xs];
                 for (int a = 0; a < rh; ++a) {
                     const float nxt = Ps[(a + 1 < rh ? a + 1 : 0) * rw + xs];
-                    *reinterpret_cast<pf2 *>(Ss + 2 * (a * rxp + x)) = pf2{cur, nxt};
+                    *reinterpret_cast<pf2 *>(Ss + 2 * a * rxp + ((2 * x) ^ pair_row_swap<G>(a))) = pf2{cur, nxt};
                     cur = nxt;
                 }
             }
@@ -557,7 +594,7 @@ scan_pairs_f32_kernel(const double *__restrict__ tbase, const double *__restrict
             int since = 0, a = k < si.rh ? k : 0;
             for (int m = 0; m < u_rows; ++m) {
                 if (u_groups > 0)
-                    pair_row<G>(acc, Ts + m * tstride, Ss + 2 * (a * rxp + l0), u_groups);
+                    pair_row<G>(acc, Ts + m * tstride, Ss + 2 * (a * rxp + l0), pair_row_swap<G>(a), u_groups);
                 a = a + 1 == si.rh ? 0 : a + 1;
                 if (++since == flush_rows || m == u_rows - 1) {
                     since = 0;
