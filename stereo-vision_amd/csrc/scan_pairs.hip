@@ -425,10 +425,25 @@ __device__ __forceinline__ BestNan wave_best(BestNan v)
     return v;
 }
 
-// Sum over the workgroup: one wavefront needs no LDS round trip.
-__device__ __forceinline__ double pair_sum(double v, double *red, int nthr)
+constexpr int PAIR_KEEP = 8;        // rows per lane that stay in registers between the two staging passes
+
+// Two sums over the workgroup at once (in place): one wavefront needs no LDS round
+// trip, two wavefronts exchange their halves through red[0..3].
+__device__ __forceinline__ void pair_sum2(double &a, double &b, double *red, int nthr)
 {
-    return nthr > WAVE ? block_sum(v, red) : wave_sum(v);
+    a = wave_sum(a);
+    b = wave_sum(b);
+    if (nthr > WAVE) {
+        const int w = threadIdx.x / WAVE;
+        __syncthreads();            // red may still be read from the previous exchange
+        if ((threadIdx.x & (WAVE - 1)) == 0) {
+            red[2 * w] = a;
+            red[2 * w + 1] = b;
+        }
+        __syncthreads();
+        a = red[0] + red[2];
+        b = red[1] + red[3];
+    }
 }
 
 template <int G>
@@ -449,6 +464,9 @@ scan_pairs_f32_kernel(const double *__restrict__ tbase, const double *__restrict
     // pair) otherwise; `lane` is the thread's index in the workgroup
     const int lane = threadIdx.x, nthr = blockDim.x;
     const int tstride = (max_side + 3) & ~3;     // template row stride in every slot
+    // staging walks the arrays in sweeps as wide as the largest side (a power of two)
+    const int cw_shift = max_side <= 8 ? 3 : max_side <= 16 ? 4 : max_side <= 32 ? 5 : 6;
+    const int lx = lane & ((1 << cw_shift) - 1), ly = lane >> cw_shift, ystep = nthr >> cw_shift;
 
     for (int64_t base = (int64_t)blockIdx.x * slots; base < npairs; base += (int64_t)gridDim.x * slots) {
         __syncthreads();   // LDS reuse across iterations
@@ -476,40 +494,68 @@ scan_pairs_f32_kernel(const double *__restrict__ tbase, const double *__restrict
             const int gcols = (rw + G - 1) / G * G;
             const int rxp = pair_row_pitch(gcols, mwp);
             float *Ts = lds + (size_t)s * slot_floats, *Ss = Ts + t_floats, *Ps = Ss + s_floats;
-            const unsigned tdiv = tw > 1 ? (unsigned)(((1ull << 32) + tw - 1) / tw) : 0u;
-            const unsigned rdiv = rw > 1 ? (unsigned)(((1ull << 32) + rw - 1) / rw) : 0u;
             // The template slot is zero beyond the pair's own rows and columns: every lane
             // of the wavefront walks the same number of rows and column groups.
             for (int i = lane; i < t_floats; i += nthr)
                 Ts[i] = 0.0f;
+            // The arrays are walked as sweeps of `ystep` rows: a lane keeps its column lx and
+            // visits rows ly, ly + ystep, ...  The first PAIR_KEEP rows of a lane stay in
+            // registers between the two passes (all of them for sides up to 32 with two
+            // wavefronts); later rows are read again.
+            double tk[PAIR_KEEP], rk[PAIR_KEEP];
+            const bool tcol = lx < tw, rcol = lx < rw;
+            const double *Tl = T + lx, *Rl = R + lx;
             // pass 1: means
             double ts = 0.0, rs = 0.0;
-            for (int i = lane; i < tn; i += nthr) {
-                const int y = tw > 1 ? (int)__umulhi((unsigned)i, tdiv) : i, x = i - y * tw;
-                ts += T[y * d.t_pitch + x];
+#pragma unroll
+            for (int j = 0; j < PAIR_KEEP; ++j) {
+                const int y = ly + j * ystep;
+                tk[j] = (tcol && y < th) ? Tl[y * d.t_pitch] : 0.0;
+                rk[j] = (rcol && y < rh) ? Rl[y * d.r_pitch] : 0.0;
+                ts += tk[j];
+                rs += rk[j];
             }
-            for (int i = lane; i < rn; i += nthr) {
-                const int y = rw > 1 ? (int)__umulhi((unsigned)i, rdiv) : i, x = i - y * rw;
-                rs += R[y * d.r_pitch + x];
+            for (int y = ly + PAIR_KEEP * ystep; y < max(th, rh); y += ystep) {
+                if (tcol && y < th)
+                    ts += Tl[y * d.t_pitch];
+                if (rcol && y < rh)
+                    rs += Rl[y * d.r_pitch];
             }
-            const double tmean = pair_sum(ts, red, nthr) / (double)tn, rmean = pair_sum(rs, red, nthr) / (double)rn;
+            pair_sum2(ts, rs, red, nthr);
+            const double tmean = ts / (double)tn, rmean = rs / (double)rn;
             // pass 2: squared deviations; the centred values go to LDS on the way (the
-            // reductions in between order them after the zero fill)
+            // reduction in between orders them after the zero fill)
             double tq = 0.0, rq = 0.0;
-            for (int i = lane; i < tn; i += nthr) {
-                const int y = tw > 1 ? (int)__umulhi((unsigned)i, tdiv) : i, x = i - y * tw;
-                const double v = T[y * d.t_pitch + x] - tmean;
-                tq += v * v;
-                if (y < mh && x < mw)
-                    Ts[y * tstride + x] = (float)v;
+#pragma unroll
+            for (int j = 0; j < PAIR_KEEP; ++j) {
+                const int y = ly + j * ystep;
+                if (tcol && y < th) {
+                    const double v = tk[j] - tmean;
+                    tq += v * v;
+                    if (y < mh && lx < mw)
+                        Ts[y * tstride + lx] = (float)v;
+                }
+                if (rcol && y < rh) {
+                    const double v = rk[j] - rmean;
+                    rq += v * v;
+                    Ps[y * rw + lx] = (float)v;
+                }
             }
-            for (int i = lane; i < rn; i += nthr) {
-                const int y = rw > 1 ? (int)__umulhi((unsigned)i, rdiv) : i, x = i - y * rw;
-                const double v = R[y * d.r_pitch + x] - rmean;
-                rq += v * v;
-                Ps[i] = (float)v;
+            for (int y = ly + PAIR_KEEP * ystep; y < max(th, rh); y += ystep) {
+                if (tcol && y < th) {
+                    const double v = Tl[y * d.t_pitch] - tmean;
+                    tq += v * v;
+                    if (y < mh && lx < mw)
+                        Ts[y * tstride + lx] = (float)v;
+                }
+                if (rcol && y < rh) {
+                    const double v = Rl[y * d.r_pitch] - rmean;
+                    rq += v * v;
+                    Ps[y * rw + lx] = (float)v;
+                }
             }
-            const double tstd = sqrt(pair_sum(tq, red, nthr) / (double)tn), rstd = sqrt(pair_sum(rq, red, nthr) / (double)rn);
+            pair_sum2(tq, rq, red, nthr);
+            const double tstd = sqrt(tq / (double)tn), rstd = sqrt(rq / (double)rn);
             const bool flat = tstd < min_std;
             if (lane == 0) {
                 info[s].tmean = tmean;
