@@ -380,22 +380,30 @@ __device__ __forceinline__ void pair_row(pf2 (&acc)[G], const float *__restrict_
     }
 }
 
-// Row pitch (in columns) of the row-pair image S: the padded surface columns, the
-// padded template width and the quads the window prefetch reads ahead.  2 mod 4
-// columns = 8 mod 16 banks from one row pair to the next but one (see pair_row_swap).
-__host__ __device__ __forceinline__ int pair_row_pitch(int gcols, int mwp)
+// Columns of the row-pair image S that hold data: the padded surface columns, the
+// padded template width and the quads the window prefetch reads ahead.
+__host__ __device__ __forceinline__ int pair_row_cols(int gcols, int mwp)
 {
-    return ((gcols + mwp + 12 + 3) & ~3) + 2;
+    return (gcols + mwp + 12 + 3) & ~3;
 }
 
-// LDS banks.  A lane reads its window 16 bytes at a time and its neighbour's window
-// starts 8 G bytes further on, so the lanes of one surface row pair touch only
-// every other (G = 4) or every fourth (G = 8) group of four banks; the next lanes of
-// a 16-lane read group work on row pairs 2, 4, 6 rows further down, a multiple of 8
-// banks away, and would collide with them.  Rows whose index has bit 1 (G = 4) or
-// bit 2 (G = 8) set are therefore stored with the two 16-byte slots of every 32
-// bytes exchanged: together with the pitch this spreads a read group over all 64
-// banks.  Returns the float offset to XOR into an in-row offset (0 or 4).
+// LDS banks.  A lane reads its window 16 bytes at a time; its neighbour's window
+// starts 8 G bytes further on, so the lanes of one surface row pair touch only every
+// other (G = 4) or every fourth (G = 8) slot of four banks, and the other lanes of
+// a 16-lane read group (lanes {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the
+// same + 32) sit on row pairs 2, 4, ... rows further down.  Two measures spread a
+// group over all 64 banks for surfaces about 32 columns wide (8 or 4 lanes per row
+// pair): the row pitch (in columns of 8 bytes) is 8 mod 16 for G = 4, which puts the
+// second half of row pair k + 1 onto the banks that the first half of row pair k
+// leaves free, and 2 mod 4 for G = 8; and rows whose index has bit 1 (G = 4) or
+// bit 2 (G = 8) set are stored with the two 16-byte slots of every 32 bytes
+// exchanged.  pair_row_swap returns the float offset to XOR into an in-row offset.
+template <int G>
+__host__ __device__ __forceinline__ int pair_row_pitch(int cols)
+{
+    return G == 4 ? ((cols + 7) & ~15) + 8 : cols + 2;
+}
+
 template <int G>
 __device__ __forceinline__ int pair_row_swap(int a)
 {
@@ -492,7 +500,7 @@ scan_pairs_f32_kernel(const double *__restrict__ tbase, const double *__restrict
             const int mh = min(th, rh), mw = min(tw, rw);
             const int mwp = (mw + 3) & ~3;
             const int gcols = (rw + G - 1) / G * G;
-            const int rxp = pair_row_pitch(gcols, mwp);
+            const int rcols = pair_row_cols(gcols, mwp), rxp = pair_row_pitch<G>(rcols);
             float *Ts = lds + (size_t)s * slot_floats, *Ss = Ts + t_floats, *Ps = Ss + s_floats;
             // The template slot is zero beyond the pair's own rows and columns: every lane
             // of the wavefront walks the same number of rows and column groups.
@@ -571,8 +579,7 @@ scan_pairs_f32_kernel(const double *__restrict__ tbase, const double *__restrict
             if (flat)
                 continue;
             // S[a][x] = (r'[a][x mod rw], r'[(a + 1) mod rh][x mod rw]) from the plain copy
-            // (the pitch's last two columns only shift the banks and hold nothing)
-            for (int x = lane; x < rxp - 2; x += nthr) {
+            for (int x = lane; x < rcols; x += nthr) {
                 const int xs = x % rw;
                 float cur = Ps[xs];
                 for (int a = 0; a < rh; ++a) {
@@ -601,7 +608,7 @@ scan_pairs_f32_kernel(const double *__restrict__ tbase, const double *__restrict
         const int mh = min(si.th, si.rh), mw = min(si.tw, si.rw);
         const int mwp = (mw + 3) & ~3;
         const int lgroups = (si.rw + G - 1) / G;
-        const int rxp = evaluate ? pair_row_pitch(lgroups * G, mwp) : 0;
+        const int rxp = evaluate ? pair_row_pitch<G>(pair_row_cols(lgroups * G, mwp)) : 0;
         const int ntasks = evaluate ? (si.rh + 1) / 2 * lgroups : 0;
         int u_rows = mh, u_groups = mwp / 4, u_tasks = ntasks;
 #pragma unroll
@@ -784,7 +791,8 @@ extern "C" int svamd_scan_pairs(const double *tbase, const double *rbase, const 
         const int G = (cols8 == cols4 && !two_waves) ? 8 : 4;
         const int gcols = G == 8 ? cols8 : cols4;
         const int t_floats = max_side * (int)side4;
-        const int rxp = pair_row_pitch(gcols, (int)side4);
+        const int rcols = pair_row_cols(gcols, (int)side4);
+        const int rxp = G == 4 ? pair_row_pitch<4>(rcols) : pair_row_pitch<8>(rcols);
         const int s_floats = 2 * max_side * rxp;
         const int slot_floats = t_floats + s_floats + max_side * (int)side4;   // template, row pairs, plain region
         const int tasks_per_slot = (max_side + 1) / 2 * (gcols / G);
