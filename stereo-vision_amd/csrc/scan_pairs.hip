@@ -69,6 +69,44 @@ __device__ __forceinline__ BestNan block_best(BestNan v, double *red_d, int *red
     return r;
 }
 
+constexpr int PAIR_KEEP = 8;        // rows per thread that stay in registers between the two staging passes
+
+// Two sums over the workgroup (up to four wavefronts) at once, in place.
+__device__ __forceinline__ void block_sum2(double &a, double &b, double *red)
+{
+    a = wave_sum(a);
+    b = wave_sum(b);
+    const int nw = (blockDim.x + WAVE - 1) / WAVE;
+    if (nw > 1) {
+        const int w = threadIdx.x / WAVE;
+        __syncthreads();            // red may still be read from the previous exchange
+        if ((threadIdx.x & (WAVE - 1)) == 0) {
+            red[2 * w] = a;
+            red[2 * w + 1] = b;
+        }
+        __syncthreads();
+        a = red[0];
+        b = red[1];
+        for (int i = 1; i < nw; ++i) {
+            a += red[2 * i];
+            b += red[2 * i + 1];
+        }
+    }
+}
+
+// Row pitch (in elements) of the float64 kernel's wrapped region image.  A lane reads
+// its window 16 bytes at a time and its neighbour's window starts 32 bytes further
+// on, so the lanes of one surface row touch every other 16-byte slot; the 16-lane
+// groups of a 16-byte LDS read ({0-3, 12-15, 20-27}, ...) span four consecutive rows.
+// A pitch of 16 mod 32 elements (128 mod 256 bytes) puts the second half of row
+// k + 1 on the banks the first half of row k leaves free, and odd rows are stored
+// with the two slots of every 32 bytes exchanged: together a group covers all banks.
+__host__ __device__ __forceinline__ int pair64_row_pitch(int rw, int mwp)
+{
+    const int c = (rw + mwp + 4 + 3) & ~3;
+    return ((c + 15) & ~31) + 16;
+}
+
 template <typename CT>
 __global__ void __launch_bounds__(256)
 scan_pairs_kernel(const double *__restrict__ tbase, const double *__restrict__ rbase,
@@ -81,6 +119,10 @@ scan_pairs_kernel(const double *__restrict__ tbase, const double *__restrict__ r
     __shared__ double red_d[4];
     __shared__ int red_i[8];   // up to 4 wavefronts per workgroup
     CT *Tb = reinterpret_cast<CT *>(smem_raw);
+    // staging walks the boxes in sweeps as wide as the largest side (a power of two)
+    const int cw_shift = max_side <= 8 ? 3 : max_side <= 16 ? 4 : max_side <= 32 ? 5 : 6;
+    const int lx = threadIdx.x & ((1 << cw_shift) - 1), ly = threadIdx.x >> cw_shift;
+    const int ystep = blockDim.x >> cw_shift;
 
     for (int64_t p = blockIdx.x; p < npairs; p += gridDim.x) {
         const PairDesc d = desc[p];
@@ -99,32 +141,65 @@ scan_pairs_kernel(const double *__restrict__ tbase, const double *__restrict__ r
         const double *R = rbase + d.r_off;
         const int tn = th * tw, rn = rh * rw;
 
+        // LDS images: template rows padded with zeros to a multiple of 4 columns,
+        // region rows wrapped horizontally and long enough for every 4-wide read
+        const int mh = min(th, rh), mw = min(tw, rw);
+        const int mwp = (mw + 3) & ~3;
+        static_assert(sizeof(CT) == 8, "the bank layout below is for 8-byte elements");
+        const int rxp = pair64_row_pitch(rw, mwp);
+        CT *Rx = Tb + mh * mwp;
+        for (int i = threadIdx.x; i < rh * rxp; i += blockDim.x)
+            Rx[i] = CT(0);
+        // Both boxes are walked as sweeps of `ystep` rows: a thread keeps its column lx and
+        // visits rows ly, ly + ystep, ...; its first PAIR_KEEP rows stay in registers
+        // between the passes, later rows are read again.
+        double tk[PAIR_KEEP], rk[PAIR_KEEP];
+        const bool tcol = lx < tw, rcol = lx < rw;
+        const double *Tl = T + lx, *Rl = R + lx;
         // pass 1: means
         double ts = 0.0, rs = 0.0;
-        for (int i = threadIdx.x; i < tn; i += blockDim.x) {
-            int y = i / tw, x = i - y * tw;
-            ts += T[y * d.t_pitch + x];
+#pragma unroll
+        for (int j = 0; j < PAIR_KEEP; ++j) {
+            const int y = ly + j * ystep;
+            tk[j] = (tcol && y < th) ? Tl[y * d.t_pitch] : 0.0;
+            rk[j] = (rcol && y < rh) ? Rl[y * d.r_pitch] : 0.0;
+            ts += tk[j];
+            rs += rk[j];
         }
-        for (int i = threadIdx.x; i < rn; i += blockDim.x) {
-            int y = i / rw, x = i - y * rw;
-            rs += R[y * d.r_pitch + x];
+        for (int y = ly + PAIR_KEEP * ystep; y < max(th, rh); y += ystep) {
+            if (tcol && y < th)
+                ts += Tl[y * d.t_pitch];
+            if (rcol && y < rh)
+                rs += Rl[y * d.r_pitch];
         }
-        const double tmean = block_sum(ts, red) / (double)tn;
-        const double rmean = block_sum(rs, red) / (double)rn;
-        // pass 2: squared deviations
+        block_sum2(ts, rs, red);
+        const double tmean = ts / (double)tn, rmean = rs / (double)rn;
+        // pass 2: squared deviations; the centred values go to LDS on the way (the
+        // reduction in between orders them after the zero fill)
         double tq = 0.0, rq = 0.0;
-        for (int i = threadIdx.x; i < tn; i += blockDim.x) {
-            int y = i / tw, x = i - y * tw;
-            double v = T[y * d.t_pitch + x] - tmean;
-            tq += v * v;
-        }
-        for (int i = threadIdx.x; i < rn; i += blockDim.x) {
-            int y = i / rw, x = i - y * rw;
-            double v = R[y * d.r_pitch + x] - rmean;
-            rq += v * v;
-        }
-        const double tstd = sqrt(block_sum(tq, red) / (double)tn);
-        const double rstd = sqrt(block_sum(rq, red) / (double)rn);
+        auto put = [&](int y, double tval, double rval) {
+            const double tv = tval - tmean;
+            if (tcol && y < th)
+                tq += tv * tv;
+            if (y < mh && lx < mwp)                     // columns mw .. mwp - 1 are zero padding
+                Tb[y * mwp + lx] = lx < mw ? (CT)tv : CT(0);
+            if (rcol && y < rh) {
+                const double v = rval - rmean;
+                rq += v * v;
+                const int sw = (y & 1) << 1;
+                Rx[y * rxp + (lx ^ sw)] = (CT)v;
+                if (lx < mw - 1)                        // the horizontal wrap
+                    Rx[y * rxp + ((lx + rw) ^ sw)] = (CT)v;
+            }
+        };
+#pragma unroll
+        for (int j = 0; j < PAIR_KEEP; ++j)
+            put(ly + j * ystep, tk[j], rk[j]);
+        for (int y = ly + PAIR_KEEP * ystep; y < max(max(th, rh), mh); y += ystep)
+            put(y, (tcol && y < th) ? Tl[y * d.t_pitch] : 0.0, (rcol && y < rh) ? Rl[y * d.r_pitch] : 0.0);
+        block_sum2(tq, rq, red);
+        const double tstd = sqrt(tq / (double)tn);
+        const double rstd = sqrt(rq / (double)rn);
         double *surf = surfaces ? surfaces + surf_off[p] : nullptr;
 
         if (tstd < min_std) {  // homogeneous template: constant surface
@@ -138,26 +213,6 @@ scan_pairs_kernel(const double *__restrict__ tbase, const double *__restrict__ r
                     out_argmax[p] = 0;
             }
             continue;
-        }
-
-        // LDS images: template rows padded with zeros to a multiple of 4 columns,
-        // region rows wrapped horizontally and long enough for every 4-wide read
-        const int mh = min(th, rh), mw = min(tw, rw);
-        const int mwp = (mw + 3) & ~3;
-        const int rxp = (rw + mwp + 4 + 3) & ~3;
-        CT *Rx = Tb + mh * mwp;
-        for (int i = threadIdx.x; i < mh * mwp; i += blockDim.x) {
-            int y = i / mwp, x = i - y * mwp;
-            Tb[i] = x < mw ? (CT)(T[y * d.t_pitch + x] - tmean) : CT(0);
-        }
-        for (int i = threadIdx.x; i < rh * rxp; i += blockDim.x) {
-            int y = i / rxp, x = i - y * rxp;
-            CT v = CT(0);
-            if (x < rw + mw - 1) {
-                int xs = x >= rw ? x - rw : x;
-                v = (CT)(R[y * d.r_pitch + xs] - rmean);
-            }
-            Rx[i] = v;
         }
         __syncthreads();
 
@@ -182,17 +237,18 @@ scan_pairs_kernel(const double *__restrict__ tbase, const double *__restrict__ r
                     rr -= rh;
                 const CT *trow = Tb + m * mwp;
                 const CT *rrow = Rx + rr * rxp + l0;
+                const int sw = (rr & 1) << 1;       // odd rows: 16-byte slots exchanged in pairs
                 CT part[4] = {CT(0), CT(0), CT(0), CT(0)};
                 CT win[8];
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    win[j] = rrow[j];
+                    win[j] = rrow[j ^ sw];
                 for (int n0 = 0; n0 < mwp; n0 += 4) {
                     CT tv[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         tv[j] = trow[n0 + j];
-                        win[4 + j] = rrow[n0 + 4 + j];
+                        win[4 + j] = rrow[n0 + 4 + (j ^ sw)];
                     }
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
@@ -432,8 +488,6 @@ __device__ __forceinline__ BestNan wave_best(BestNan v)
     }
     return v;
 }
-
-constexpr int PAIR_KEEP = 8;        // rows per lane that stay in registers between the two staging passes
 
 // Two sums over the workgroup at once (in place): one wavefront needs no LDS round
 // trip, two wavefronts exchange their halves through red[0..3].
@@ -775,7 +829,7 @@ extern "C" int svamd_scan_pairs(const double *tbase, const double *rbase, const 
                "scan_pairs: unknown accumulation precision %d", acc_precision);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const size_t side4 = ((size_t)max_side + 3) & ~(size_t)3;
-    const size_t elems = (size_t)max_side * side4 + (size_t)max_side * (((size_t)max_side + side4 + 4 + 3) & ~(size_t)3);
+    const size_t elems = (size_t)max_side * side4 + (size_t)max_side * pair64_row_pitch(max_side, (int)side4);
     // one task per 4 surface elements of a row: small windows get small workgroups
     const int tasks = max_side * ((max_side + 3) / 4);
     const int threads = tasks <= 64 ? 64 : tasks <= 128 ? 128 : 256;
