@@ -154,10 +154,9 @@ def config3():
     emit(config=3, what='sequence_scan portal config, synthetic 960x1080', seconds=dt, windows=nwin,
          pairs=pairs, nonzero=moved, pairs_per_s=pairs / dt, surface_elems_per_s=pairs * 144 / dt)
     # device-only time of the pair kernel for the cone scan
-    windows, tb, rb = sv_image_comparison._stage0_windows(left, right, 12, 12, (11, 1), (1, 0), 0)
+    windows, stage_boxes = sv_image_comparison._stage0_windows(left, right, 12, 12, (11, 1), (1, 0), 0)
     batch = sv_image_comparison._StageBatch(left.shape[1], right.shape[1])
-    for (wid, w), t, rbx in zip(windows.items(), tb, rb):
-        batch.add(t, w['centre'], w['target_regions'], rbx)
+    batch.add_arrays(*stage_boxes)
     desc = nv.to_device(batch.desc())
     dl, dr = nv.to_device(left), nv.to_device(right)
     out = nv.empty(desc.shape[0], torch.float64)
@@ -377,7 +376,7 @@ def config_prepare():
         ms = device_ms(lambda: nv.call('svamd_downsample', nv.ptr(src), code, h, w, h // 2, w // 2, nv.ptr(out),
                                        nv.ptr(ws), nbytes, nv.stream_ptr()))
         moved = h * w * (1 if code == nv.U8 else 8) + (h // 2) * (w // 2) * 8
-        emit(config='N3', what=f'downsample by 2, 4096x4096 {label} -> 2048x2048 float64 (device, 4 kernels)',
+        emit(config='N3', what=f'downsample by 2, 4096x4096 {label} -> 2048x2048 float64 (device: value range, weights, fused filter + sampling)',
              ms=ms, algorithmic_gbytes_per_s=moved / ms / 1e6)
     host = grey8.cpu().numpy()
     dt, _ = timed(utils.downsample, host, 2)

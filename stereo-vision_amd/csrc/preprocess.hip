@@ -23,7 +23,7 @@
 namespace svamd {
 
 constexpr int PRE_MAX_RADIUS = 255;
-constexpr int PRE_PARTIALS = 256;
+constexpr int PRE_PARTIALS = 2048;
 
 template <typename T> __device__ __forceinline__ double as_unit(T v);
 template <> __device__ __forceinline__ double as_unit<uint8_t>(uint8_t v)
@@ -119,15 +119,50 @@ gaussian_axis_kernel(const T *__restrict__ in, int H, int W, const double *__res
     out[idx] = acc;
 }
 
-// smallest and largest non-NaN value per block -> partial[2 b], partial[2 b + 1]
+// Smallest and largest non-NaN value of the image (as the scaled values the resize
+// works on): per-block partials from 16-byte loads, then one block folds them into
+// partial[0], partial[1].
+template <typename T> struct Pack16;
+template <> struct Pack16<uint8_t> {
+    static constexpr int N = 16;
+    uint4 raw;
+    __device__ __forceinline__ double get(int i) const
+    {
+        const uint32_t w = i < 4 ? raw.x : i < 8 ? raw.y : i < 12 ? raw.z : raw.w;
+        return as_unit<uint8_t>((uint8_t)(w >> (8 * (i & 3))));
+    }
+};
+template <> struct Pack16<double> {
+    static constexpr int N = 2;
+    double2 raw;
+    __device__ __forceinline__ double get(int i) const { return i ? raw.y : raw.x; }
+};
+
 template <typename T>
 __global__ void __launch_bounds__(256)
 range_partial_kernel(const T *__restrict__ in, int64_t total, double *__restrict__ partial)
 {
     double lo = INFINITY, hi = -INFINITY;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    constexpr int N = Pack16<T>::N;
+    const int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, nthreads = (int64_t)gridDim.x * blockDim.x;
+    int64_t done = 0;
+    if ((reinterpret_cast<uintptr_t>(in) & 15) == 0) {
+        const int64_t packs = total / N;
+        const Pack16<T> *pin = reinterpret_cast<const Pack16<T> *>(in);
+        for (int64_t i = tid; i < packs; i += nthreads) {
+            const Pack16<T> p = pin[i];
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                const double v = p.get(k);
+                lo = fmin(lo, v);           // fmin / fmax drop NaNs
+                hi = fmax(hi, v);
+            }
+        }
+        done = packs * N;
+    }
+    for (int64_t i = done + tid; i < total; i += nthreads) {
         const double v = as_unit<T>(in[i]);
-        lo = fmin(lo, v);           // fmin / fmax drop NaNs
+        lo = fmin(lo, v);
         hi = fmax(hi, v);
     }
     __shared__ double slo[256], shi[256];
@@ -144,6 +179,30 @@ range_partial_kernel(const T *__restrict__ in, int64_t total, double *__restrict
     if (threadIdx.x == 0) {
         partial[2 * blockIdx.x] = slo[0];
         partial[2 * blockIdx.x + 1] = shi[0];
+    }
+}
+
+__global__ void __launch_bounds__(256) range_final_kernel(double *__restrict__ partial, int npartial)
+{
+    double lo = INFINITY, hi = -INFINITY;
+    for (int i = threadIdx.x; i < npartial; i += blockDim.x) {
+        lo = fmin(lo, partial[2 * i]);
+        hi = fmax(hi, partial[2 * i + 1]);
+    }
+    __shared__ double slo[256], shi[256];
+    slo[threadIdx.x] = lo;
+    shi[threadIdx.x] = hi;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            slo[threadIdx.x] = fmin(slo[threadIdx.x], slo[threadIdx.x + s]);
+            shi[threadIdx.x] = fmax(shi[threadIdx.x], shi[threadIdx.x + s]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        partial[0] = slo[0];
+        partial[1] = shi[0];
     }
 }
 
@@ -206,6 +265,115 @@ zoom_linear_kernel(const T *__restrict__ in, int H, int W, int OH, int OW, doubl
     out[idx] = t;
 }
 
+// The filter and the interpolation in one kernel, for images that shrink along both
+// axes: a workgroup produces a tile of the output from an input tile staged in LDS
+// (mirrored at the image borders while loading, so the passes inside need no border
+// logic), filtered along axis 0, then along axis 1, then sampled.  The operations
+// and their order are those of the separate passes: results are identical.
+struct FusedGeom {
+    int H, W, OH, OW;
+    double zoom_y, zoom_x;
+    int ry, rx;          // filter radii
+    int to_y, to_x;      // output tile
+    int fr_y, fr_x;      // filtered rows / columns a tile can need at most
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+downsample_fused_kernel(const T *__restrict__ in, FusedGeom g, const double *__restrict__ wy,
+                        const double *__restrict__ wx, const double *__restrict__ partial, int npartial,
+                        double *__restrict__ out)
+{
+    extern __shared__ __align__(16) double fused_lds[];
+    __shared__ double range[2];
+    double *A = fused_lds;                                          // input tile, later the filtered tile
+    double *B = A + (size_t)(g.fr_y + 2 * g.ry) * (g.fr_x + 2 * g.rx);   // after the axis-0 pass
+    if (threadIdx.x < 2) {
+        double v = threadIdx.x == 0 ? INFINITY : -INFINITY;
+        for (int i = 0; i < npartial; ++i)
+            v = threadIdx.x == 0 ? fmin(v, partial[2 * i]) : fmax(v, partial[2 * i + 1]);
+        range[threadIdx.x] = v;
+    }
+    const int oy0 = blockIdx.y * g.to_y, ox0 = blockIdx.x * g.to_x;
+    const int oy1 = min(oy0 + g.to_y, g.OH) - 1, ox1 = min(ox0 + g.to_x, g.OW) - 1;
+    // filtered rows / columns this tile samples: floor(first coordinate) .. floor(last) + 1
+    const int fy0 = (int)floor(__dadd_rn(__dmul_rn(oy0 + 0.5, g.zoom_y), -0.5));
+    const int fx0 = (int)floor(__dadd_rn(__dmul_rn(ox0 + 0.5, g.zoom_x), -0.5));
+    const int nfy = (int)floor(__dadd_rn(__dmul_rn(oy1 + 0.5, g.zoom_y), -0.5)) + 2 - fy0;
+    const int nfx = (int)floor(__dadd_rn(__dmul_rn(ox1 + 0.5, g.zoom_x), -0.5)) + 2 - fx0;
+    const int ih = nfy + 2 * g.ry, iw = nfx + 2 * g.rx;
+
+    for (int i = threadIdx.x; i < ih * iw; i += blockDim.x) {
+        const int r = i / iw, c = i - r * iw;
+        const int gy = mirror_index(fy0 - g.ry + r, g.H), gx = mirror_index(fx0 - g.rx + c, g.W);
+        A[i] = as_unit<T>(in[(int64_t)gy * g.W + gx]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nfy * iw; i += blockDim.x) {
+        const int r = i / iw, c = i - r * iw;
+        const double *col = A + (r + g.ry) * iw + c;
+        double acc = __dmul_rn(col[0], wy[g.ry]);
+        for (int k = g.ry; k >= 1; --k)
+            acc = __dadd_rn(acc, __dmul_rn(__dadd_rn(col[-k * iw], col[k * iw]), wy[g.ry - k]));
+        B[i] = acc;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nfy * nfx; i += blockDim.x) {
+        const int r = i / nfx, c = i - r * nfx;
+        const double *row = B + r * iw + c + g.rx;
+        double acc = __dmul_rn(row[0], wx[g.rx]);
+        for (int k = g.rx; k >= 1; --k)
+            acc = __dadd_rn(acc, __dmul_rn(__dadd_rn(row[-k], row[k]), wx[g.rx - k]));
+        A[i] = acc;
+    }
+    __syncthreads();
+    const int tw = ox1 - ox0 + 1, tcount = (oy1 - oy0 + 1) * tw;
+    for (int i = threadIdx.x; i < tcount; i += blockDim.x) {
+        const int oy = oy0 + i / tw, ox = ox0 + i % tw;
+        const double cy = __dadd_rn(__dmul_rn(oy + 0.5, g.zoom_y), -0.5);
+        const double cx = __dadd_rn(__dmul_rn(ox + 0.5, g.zoom_x), -0.5);
+        const double fy = floor(cy), fx = floor(cx);
+        const double wy0 = 1.0 - (cy - fy), wy1 = 1.0 - wy0;
+        const double wx0 = 1.0 - (cx - fx), wx1 = 1.0 - wx0;
+        const double *r0 = A + ((int)fy - fy0) * nfx + ((int)fx - fx0), *r1 = r0 + nfx;
+        double t = 0.0;
+        t = __dadd_rn(t, __dmul_rn(__dmul_rn(r0[0], wy0), wx0));
+        t = __dadd_rn(t, __dmul_rn(__dmul_rn(r0[1], wy0), wx1));
+        t = __dadd_rn(t, __dmul_rn(__dmul_rn(r1[0], wy1), wx0));
+        t = __dadd_rn(t, __dmul_rn(__dmul_rn(r1[1], wy1), wx1));
+        if (t < range[0])
+            t = range[0];
+        else if (t > range[1])
+            t = range[1];
+        out[(int64_t)oy * g.OW + ox] = t;
+    }
+}
+
+constexpr size_t FUSED_LDS_LIMIT = 64 * 1024;
+
+// Output tile for the fused kernel, or false when even a 4 x 4 tile's input does not
+// fit (very large reduction factors): the separate passes serve those.
+static bool fused_geometry(int H, int W, int OH, int OW, int ry, int rx, FusedGeom &g, size_t &lds)
+{
+    g.H = H; g.W = W; g.OH = OH; g.OW = OW;
+    g.zoom_y = (double)H / OH; g.zoom_x = (double)W / OW;
+    g.ry = ry; g.rx = rx;
+    g.to_y = 16; g.to_x = 32;
+    for (;;) {
+        g.fr_y = (int)ceil(g.to_y * g.zoom_y) + 2;
+        g.fr_x = (int)ceil(g.to_x * g.zoom_x) + 2;
+        lds = sizeof(double) * ((size_t)(g.fr_y + 2 * ry) * (g.fr_x + 2 * rx) + (size_t)g.fr_y * (g.fr_x + 2 * rx));
+        if (lds <= FUSED_LDS_LIMIT)
+            return true;
+        if (g.to_x <= 4 && g.to_y <= 4)
+            return false;
+        if (g.to_x >= g.to_y)
+            g.to_x /= 2;
+        else
+            g.to_y /= 2;
+    }
+}
+
 static int gaussian_radius(double sigma)
 {
     return (int)(4.0 * sigma + 0.5);
@@ -221,14 +389,33 @@ static int downsample_launch(const T *image, int H, int W, int OH, int OW, doubl
     const bool anti_alias = OH < H || OW < W;
     Carver ws(workspace);
     double *partial = ws.take<double>(2 * PRE_PARTIALS);
-    double *weights = ws.take<double>(2 * PRE_MAX_RADIUS + 1);
+    double *weights = ws.take<double>(2 * (2 * PRE_MAX_RADIUS + 1));
     double *tmp0 = ws.take<double>((size_t)total);
     double *tmp1 = ws.take<double>((size_t)total);
 
     const unsigned grid_in = (unsigned)((total + 255) / 256);
-    const int npartial = (int)(grid_in < (unsigned)PRE_PARTIALS ? grid_in : (unsigned)PRE_PARTIALS);
-    hipLaunchKernelGGL(range_partial_kernel<T>, dim3(npartial), dim3(256), 0, st, image, total, partial);
+    const int nblocks = (int)(grid_in < (unsigned)PRE_PARTIALS ? grid_in : (unsigned)PRE_PARTIALS);
+    hipLaunchKernelGGL(range_partial_kernel<T>, dim3(nblocks), dim3(256), 0, st, image, total, partial);
     SV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(range_final_kernel, dim3(1), dim3(256), 0, st, partial, nblocks);
+    SV_LAUNCH_CHECK();
+    const int npartial = 1;     // the consumers read the folded pair
+
+    FusedGeom fg;
+    size_t fused_lds = 0;
+    if (OH < H && OW < W && fused_geometry(H, W, OH, OW, gaussian_radius(sy), gaussian_radius(sx), fg, fused_lds)) {
+        // weights of the two axes side by side (an axis with sigma 0 gets the single weight 1)
+        double *wy = weights, *wx = weights + (2 * PRE_MAX_RADIUS + 1);
+        hipLaunchKernelGGL(gaussian_weights_kernel, dim3(1), dim3(256), 0, st, sy, fg.ry, wy);
+        SV_LAUNCH_CHECK();
+        hipLaunchKernelGGL(gaussian_weights_kernel, dim3(1), dim3(256), 0, st, sx, fg.rx, wx);
+        SV_LAUNCH_CHECK();
+        dim3 grid((unsigned)((OW + fg.to_x - 1) / fg.to_x), (unsigned)((OH + fg.to_y - 1) / fg.to_y));
+        hipLaunchKernelGGL(downsample_fused_kernel<T>, grid, dim3(256), fused_lds, st, image, fg, wy, wx, partial,
+                           npartial, out);
+        SV_LAUNCH_CHECK();
+        return SVAMD_OK;
+    }
 
     const double *filtered = nullptr;       // null: the input itself
     // scipy skips an axis whose sigma is below 1e-15
@@ -287,7 +474,7 @@ extern "C" size_t svamd_downsample_workspace_bytes(int H, int W)
 {
     if (H <= 0 || W <= 0)
         return 0;
-    return align_up(2 * PRE_PARTIALS * sizeof(double), 256) + align_up((2 * PRE_MAX_RADIUS + 1) * sizeof(double), 256) +
+    return align_up(2 * PRE_PARTIALS * sizeof(double), 256) + align_up(2 * (2 * PRE_MAX_RADIUS + 1) * sizeof(double), 256) +
            2 * align_up((size_t)H * W * sizeof(double), 256);
 }
 

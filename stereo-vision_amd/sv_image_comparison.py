@@ -8,6 +8,9 @@ region enumeration stays on the host; every (template, region) correlation of
 a stage, its maximum and the per-window selection rule run on the GPU in two
 launches (libsvamd: svamd_scan_pairs, svamd_scan_fold).
 '''
+import contextlib
+import gc
+
 import numpy as np
 
 import correlation_spectral
@@ -103,13 +106,69 @@ def _axis_candidates(starts, window, span_hw, count, limit):
     own_rejected = (centres + half <= 0) | (centres - half > limit)
     return dict(centres=centres.tolist(), grid=grid.tolist(), rejected=rejected.tolist(),
                 begin=begin.tolist(), end=end.tolist(), own_begin=own_begin.tolist(),
-                own_end=own_end.tolist(), own_rejected=own_rejected.tolist())
+                own_end=own_end.tolist(), own_rejected=own_rejected.tolist(),
+                arrays=dict(rejected=rejected, begin=begin, end=end, own_begin=own_begin, own_end=own_end,
+                            own_rejected=own_rejected, at_centre=grid == centres[:, None]))
+
+
+def _stage0_boxes(ax, ay, xs, ys, x_window, y_window, image_width, image_height):
+    '''The boxes of _stage0_windows as arrays, without a Python loop over regions:
+    template boxes [windows, 4], region boxes [pairs, 4] (x_start, x_end, y_start,
+    y_end) in the order _stage0_windows lists the regions, the number of regions per
+    window, and which pair is the window's own position.'''
+    X, Y = ax['arrays'], ay['arrays']
+    ncol, nx = X['begin'].shape
+    nrow, ny = Y['begin'].shape
+    slots = 1 + ny * nx
+    boxes = np.empty((nrow, ncol, slots, 4), dtype=np.int64)
+    valid = np.empty((nrow, ncol, slots), dtype=bool)
+    # slot 0: the window's own position
+    boxes[:, :, 0, 0] = X['own_begin'][None, :]
+    boxes[:, :, 0, 1] = X['own_end'][None, :]
+    boxes[:, :, 0, 2] = Y['own_begin'][:, None]
+    boxes[:, :, 0, 3] = Y['own_end'][:, None]
+    valid[:, :, 0] = ~(X['own_rejected'][None, :] | Y['own_rejected'][:, None])
+    # slots 1 + j * nx + i: the scheme grid, row by row
+    grid = boxes[:, :, 1:, :].reshape(nrow, ncol, ny, nx, 4)
+    grid[..., 0] = X['begin'][None, :, None, :]
+    grid[..., 1] = X['end'][None, :, None, :]
+    grid[..., 2] = Y['begin'][:, None, :, None]
+    grid[..., 3] = Y['end'][:, None, :, None]
+    valid[:, :, 1:] = ~(X['rejected'][None, :, None, :] | Y['rejected'][:, None, :, None] |
+                        (X['at_centre'][None, :, None, :] & Y['at_centre'][:, None, :, None])
+                        ).reshape(nrow, ncol, ny * nx)
+    counts = valid.sum(axis=2).ravel()
+    region_boxes = boxes[valid]
+    centre = np.zeros(len(region_boxes), dtype=bool)
+    first = np.concatenate([[0], np.cumsum(counts)[:-1]])
+    own = valid[:, :, 0].ravel()
+    centre[first[own & (counts > 0)]] = True
+    template_boxes = np.empty((nrow, ncol, 4), dtype=np.int64)
+    template_boxes[:, :, 0] = xs[None, :]
+    template_boxes[:, :, 1] = np.minimum(xs + x_window, image_width)[None, :]
+    template_boxes[:, :, 2] = ys[:, None]
+    template_boxes[:, :, 3] = np.minimum(ys + y_window, image_height)[:, None]
+    return template_boxes.reshape(-1, 4), region_boxes, counts, centre
+
+
+@contextlib.contextmanager
+def _gc_paused():
+    '''Enumerating a stage creates hundreds of thousands of small dicts and tuples,
+    none of them cyclic; the cycle collector's generational passes over them cost
+    as much again as building them.'''
+    was_enabled = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was_enabled:
+            gc.enable()
 
 
 def _stage0_windows(template_image, region_image, x_window, y_window, scheme, scheme_shift_size,
                     window_overlap):
-    '''Windows of the first stage plus, per window, the template box and the
-    region boxes (x_start, x_end, y_start, y_end).  Same enumeration as the
+    '''Windows of the first stage plus the arrays of _stage0_boxes (template boxes,
+    region boxes, regions per window, own-position flags).  Same enumeration as the
     reference's double loop with region_pairs / get_window_boundaries per window,
     but the candidate grids and their clipping are computed once per window
     column and once per window row.'''
@@ -130,7 +189,7 @@ def _stage0_windows(template_image, region_image, x_window, y_window, scheme, sc
     ay = _axis_candidates(ys, y_window, y_span_hw, scheme[1], image_height)
     size = (x_window, y_window)
 
-    windows, template_boxes, region_boxes = {}, [], []
+    windows = {}
     window_id = 0
     for row, y in enumerate(ys.tolist()):
         y_centre = ay['centres'][row]
@@ -141,14 +200,13 @@ def _stage0_windows(template_image, region_image, x_window, y_window, scheme, sc
             x_grid, x_rej = ax['grid'][column], ax['rejected'][column]
             x_begin, x_end = ax['begin'][column], ax['end'][column]
             centre = (x_centre, y_centre)
-            regions, boxes = [], []
+            regions = []
             # the window's own position first, then the scheme grid row by row
             if not (ax['own_rejected'][column] or ay['own_rejected'][row]):
                 x0, x1 = ax['own_begin'][column], ax['own_end'][column]
                 y0, y1 = ay['own_begin'][row], ay['own_end'][row]
                 regions.append({'centre': centre, 'size': (x1 - x0, y1 - y0),
                                 'image_slice': region_image[y0:y1, x0:x1]})
-                boxes.append((x0, x1, y0, y1))
             for j, _y in enumerate(y_grid):
                 at_row = _y == y_centre
                 y0, y1 = y_begin[j], y_end[j]
@@ -158,7 +216,6 @@ def _stage0_windows(template_image, region_image, x_window, y_window, scheme, sc
                     x0, x1 = x_begin[i], x_end[i]
                     regions.append({'centre': (_x, _y), 'size': (x1 - x0, y1 - y0),
                                     'image_slice': region_image[y0:y1, x0:x1]})
-                    boxes.append((x0, x1, y0, y1))
             windows[window_id] = {
                 'row': row,
                 'column': column,
@@ -167,10 +224,8 @@ def _stage0_windows(template_image, region_image, x_window, y_window, scheme, sc
                 'image_slice': template_image[y:y + y_window, x:x + x_window],
                 'target_regions': regions,
             }
-            template_boxes.append((x, min(x + x_window, image_width), y, min(y + y_window, image_height)))
-            region_boxes.append(boxes)
             window_id += 1
-    return windows, template_boxes, region_boxes
+    return windows, _stage0_boxes(ax, ay, xs, ys, x_window, y_window, image_width, image_height)
 
 
 def whole_image_search_regions(template_image, region_image, x_window, y_window,
@@ -376,6 +431,15 @@ class _StageBatch:
         self.template_boxes, self.region_boxes, self.centre, self.offsets = [], [], [], [0]
         self._desc = None
 
+    def add_arrays(self, template_boxes, region_boxes, counts, centre):
+        '''A whole stage at once, from the arrays of _stage0_boxes.'''
+        assert not self.template_boxes
+        self.template_boxes = template_boxes
+        self.region_boxes = region_boxes
+        self.centre = centre
+        self.offsets = np.concatenate([[0], np.cumsum(counts)]).tolist()
+        self._desc = None
+
     def add(self, template_box, centre, regions, region_boxes):
         self.template_boxes.append(template_box)
         self.region_boxes.extend(region_boxes)
@@ -416,6 +480,11 @@ def sequence_scan(left_image, right_image, scan_config):
     '''Compares a left and a right image by window searching over the stages of
     one sequence and returns one dict of windows per stage (reference
     sv_image_comparison.py:21-117).'''
+    with _gc_paused():
+        return _sequence_scan(left_image, right_image, scan_config)
+
+
+def _sequence_scan(left_image, right_image, scan_config):
     seq_results = []
     image_width = left_image.shape[1]
     image_height = left_image.shape[0]
@@ -433,7 +502,7 @@ def sequence_scan(left_image, right_image, scan_config):
     for stage, stage_config in enumerate(scan_config):
         windows = {}
         if stage == 0:
-            windows, template_boxes, region_boxes = _stage0_windows(
+            windows, stage_boxes = _stage0_windows(
                 template_image=left_image,
                 region_image=right_image,
                 x_window=stage_config['window_width'],
@@ -447,9 +516,7 @@ def sequence_scan(left_image, right_image, scan_config):
                 window_info['stage_centres'] = [window_info['centre']]
                 window_info['stage_sizes'] = [window_info['size']]
             batch = _StageBatch(image_width, right_image.shape[1])
-            for (window_id, window_info), tbox, rboxes in zip(windows.items(), template_boxes,
-                                                              region_boxes):
-                batch.add(tbox, window_info['centre'], window_info['target_regions'], rboxes)
+            batch.add_arrays(*stage_boxes)
             if batched and batch.max_side() <= nv.PAIR_MAX_SIDE:
                 best_pair, best_val = batch.run(*resident(), threshold)
                 for i, (window_id, window_info) in enumerate(windows.items()):
