@@ -675,6 +675,26 @@ def test_downsample_vs_oracle(mods, oracle, shape, factor, kind):
     assert np.array_equal(got.resident.cpu().numpy(), np.asarray(got), equal_nan=True)
 
 
+@pytest.mark.parametrize('shape,out_shape', [((96, 200), (96, 100)), ((120, 64), (40, 64)), ((400, 400), (10, 10)),
+                                             ((300, 500), (100, 125))])
+def test_downsample_c_abi_shapes(mods, oracle, shape, out_shape):
+    '''Output shapes the Python wrapper never asks for: one axis kept (separate
+    filter passes), a reduction too large for the fused tile, unequal factors.'''
+    nv = mods['n']
+    torch = nv.torch_cuda()
+    rng = np.random.default_rng(shape[0] + out_shape[1])
+    image = rng.normal(size=shape) * 20 + 100
+    d_in = nv.to_device(image)
+    out = nv.empty(out_shape, torch.float64)
+    nbytes = nv.load_library().svamd_downsample_workspace_bytes(*shape)
+    ws = nv.workspace(nbytes)
+    nv.call('svamd_downsample', nv.ptr(d_in), nv.F64, shape[0], shape[1], out_shape[0], out_shape[1], nv.ptr(out),
+            nv.ptr(ws), nbytes, nv.stream_ptr())
+    want = oracle.resize(image, out_shape)
+    got = out.cpu().numpy()
+    assert np.max(np.abs(got - want)) <= RESIZE_TOL * np.max(np.abs(want))
+
+
 def test_downsample_rejects(mods):
     with pytest.raises(TypeError):
         mods['u'].downsample(np.zeros((8, 8), np.int32), 2)
