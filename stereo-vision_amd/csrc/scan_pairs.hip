@@ -699,10 +699,14 @@ scan_pairs_f32_kernel(const double *__restrict__ tbase, const double *__restrict
                 d0[j] = d1[j] = 0.0;
             }
             int since = 0, a = k < si.rh ? k : 0;
+            const float *srow = Ss + 2 * (a * rxp + l0), *trow = Ts;      // walked, not recomputed, row by row
             for (int m = 0; m < u_rows; ++m) {
                 if (u_groups > 0)
-                    pair_row<G>(acc, Ts + m * tstride, Ss + 2 * (a * rxp + l0), pair_row_swap<G>(a), u_groups);
-                a = a + 1 == si.rh ? 0 : a + 1;
+                    pair_row<G>(acc, trow, srow, pair_row_swap<G>(a), u_groups);
+                trow += tstride;
+                const bool wrap = a + 1 == si.rh;
+                a = wrap ? 0 : a + 1;
+                srow = wrap ? Ss + 2 * l0 : srow + 2 * rxp;
                 if (++since == flush_rows || m == u_rows - 1) {
                     since = 0;
 #pragma unroll
