@@ -344,6 +344,17 @@ constexpr int F1K_LDS = F1K + 4 * (F1K / 64);     // padded elements per sequenc
 
 __device__ __forceinline__ int f1k_idx(int p) { return p + 4 * (p >> 6); }
 
+// Layout of the half spectra between the 1024 x 1024 passes: [pair][group of 4
+// columns][row][4 columns].  The column pass works on one group at a time, which is
+// then 32 KB of consecutive memory instead of 1024 row pieces of 32 bytes (a
+// quarter of a 128-byte line each); the row passes touch 32 consecutive bytes per
+// row and group either way.  A pair keeps the footprint of the row-major layout
+// (F1K x hp elements, hp >= 516).
+__device__ __forceinline__ int64_t f1k_spec_index(int y, int k)
+{
+    return (int64_t)(k >> 2) * (F1K * 4) + y * 4 + (k & 3);
+}
+
 __device__ __forceinline__ void dif4(float2 &a, float2 &b, float2 &c, float2 &d, float2 w1, float2 w2, float2 w3)
 {
     const float2 apc = cadd(a, c), amc = csub(a, c), bpd = cadd(b, d), bmd = csub(b, d);
@@ -541,12 +552,14 @@ fft_row_sums_kernel(const double *__restrict__ row_sums, int H, FftStats *__rest
     }
 }
 
-// pass 1, W = 1024: a wavefront transforms F1K_ROWS_PER_WAVE consecutive image rows,
-// one at a time, with the next row's pixels already on their way while the current
-// row is transformed (a wavefront that loads, transforms and stores a single row
-// spends most of its life waiting for memory).  Four wavefronts per workgroup.
-// Also produces each row's exact sums of (x - centre) and (x - centre)^2 of both
-// arrays.
+// pass 1, W = 1024: a workgroup of four wavefronts takes 16 consecutive image rows,
+// four at a time (one per wavefront), with every wavefront's next row already on its
+// way while the current one is transformed (a wavefront that loads, transforms and
+// stores a single row spends most of its life waiting for memory).  After the four
+// transforms the whole workgroup splits the packed spectra and stores them: four rows
+// x four columns of a column group are one 128-byte line (f1k_spec_index), written by
+// eight neighbouring threads.  Also produces each row's exact sums of (x - centre) and
+// (x - centre)^2 of both arrays.
 constexpr int F1K_ROWS_PER_WAVE = 4;
 
 __global__ void __launch_bounds__(256)
@@ -558,18 +571,17 @@ f1k_rows_forward_kernel(const float *__restrict__ t, int th, int tw_, const floa
     __shared__ float2 lds[4 * F1K_LDS];
     __shared__ float2 twiddle[F1K];                 // LDS copy: gathered reads stay off the memory pipeline
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int y_first = (blockIdx.x * 4 + wave) * F1K_ROWS_PER_WAVE, pair = blockIdx.y;
+    const int y_block = blockIdx.x * 4 * F1K_ROWS_PER_WAVE, pair = blockIdx.y;   // H is a multiple of 16
     for (int i = threadIdx.x; i < F1K; i += 256)
         twiddle[i] = twiddle_table[i];
     __syncthreads();
-    if (y_first >= H)
-        return;
-    const int y_end = min(y_first + F1K_ROWS_PER_WAVE, H);
     float2 *x = lds + wave * F1K_LDS;
     const float *tbase = t + (int64_t)pair * th * tw_;
     const float *rbase = r + (int64_t)pair * H * F1K;
     const float tc = stats[pair].t_centre, rc = stats[pair].r_centre;
     const int mw = min(tw_, F1K), mh = min(th, H);
+    float2 *ot = spec_t + (int64_t)pair * H * hp;
+    float2 *orr = spec_r + (int64_t)pair * H * hp;
 
     float tn[16], rn[16];           // the next row, raw
     auto fetch = [&](int y) {
@@ -583,8 +595,9 @@ f1k_rows_forward_kernel(const float *__restrict__ t, int th, int tw_, const floa
             rn[m] = rrow[xx];
         }
     };
-    fetch(y_first);
-    for (int y = y_first; y < y_end; ++y) {
+    fetch(y_block + wave);
+    for (int j = 0; j < F1K_ROWS_PER_WAVE; ++j) {
+        const int y_group = y_block + 4 * j, y = y_group + wave;
         float2 v[16];
         // per-lane partial sums of 16 centred values fit float32 comfortably; lanes and
         // rows are combined in float64
@@ -598,8 +611,8 @@ f1k_rows_forward_kernel(const float *__restrict__ t, int th, int tw_, const floa
             frs += rv;
             frq = fmaf(rv, rv, frq);
         }
-        if (y + 1 < y_end)
-            fetch(y + 1);
+        if (j + 1 < F1K_ROWS_PER_WAVE)
+            fetch(y + 4);
         double ts = fts, tq = ftq, rs = frs, rq = frq;
         // template statistics cover the whole template: add what the crop to the
         // region's shape left out (columns beyond W, rows beyond H)
@@ -621,20 +634,33 @@ f1k_rows_forward_kernel(const float *__restrict__ t, int th, int tw_, const floa
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 x[f1k_idx(4 * (lane + 64 * u) + e)] = v[4 * u + e];
-        __builtin_amdgcn_wave_barrier();
-        float2 *ot = spec_t + ((int64_t)pair * H + y) * hp;
-        float2 *orr = spec_r + ((int64_t)pair * H + y) * hp;
+        __syncthreads();
+        // split z = fft(t + i r) into the two half spectra; item -> (column group, row, half)
+        constexpr int GROUPS = F1K / 2 / 4 + 1;             // 129: columns 0 .. 512
+        for (int item = threadIdx.x; item < GROUPS * 8; item += 256) {
+            const int half = item & 1, w = (item >> 1) & 3, k0 = (item >> 3) * 4 + 2 * half;
+            if (k0 > F1K / 2)
+                continue;
+            const float2 *xs = lds + w * F1K_LDS;
+            float2 ta[2], ra[2];
 #pragma unroll
-        for (int i = 0; i <= 8; ++i) {
-            const int k = lane + 64 * i;
-            if (k <= F1K / 2) {
-                const float2 zk = x[f1k_idx(digit_reverse(k, 10))];
-                const float2 zm = x[f1k_idx(digit_reverse((F1K - k) & (F1K - 1), 10))];
-                ot[k] = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
-                orr[k] = make_float2(0.5f * (zk.y + zm.y), 0.5f * (zm.x - zk.x));
+            for (int c = 0; c < 2; ++c) {
+                const int k = min(k0 + c, F1K / 2);
+                const float2 zk = xs[f1k_idx(digit_reverse(k, 10))];
+                const float2 zm = xs[f1k_idx(digit_reverse((F1K - k) & (F1K - 1), 10))];
+                ta[c] = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
+                ra[c] = make_float2(0.5f * (zk.y + zm.y), 0.5f * (zm.x - zk.x));
+            }
+            const int64_t at = f1k_spec_index(y_group + w, k0);
+            if (k0 + 1 <= F1K / 2) {
+                *reinterpret_cast<float4 *>(ot + at) = make_float4(ta[0].x, ta[0].y, ta[1].x, ta[1].y);
+                *reinterpret_cast<float4 *>(orr + at) = make_float4(ra[0].x, ra[0].y, ra[1].x, ra[1].y);
+            } else {
+                ot[at] = ta[0];
+                orr[at] = ra[0];
             }
         }
-        __builtin_amdgcn_wave_barrier();    // the next row reuses x
+        __syncthreads();    // the next rows reuse the transform buffers
     }
 }
 
@@ -653,6 +679,7 @@ f1k_rows_forward_kernel(const float *__restrict__ t, int th, int tw_, const floa
 #define SV_F1K_MINWAVES 4
 #endif
 constexpr int F1K_TILE = SV_F1K_TILE;
+static_assert(F1K_TILE == 4, "the spectrum layout groups columns in fours");
 constexpr int F1K_COL = F1K_LDS + 2;              // column stride in LDS (bank spread for the transpose)
 constexpr int F1K_QUADS = F1K * (F1K_TILE / 2) / (64 * F1K_TILE);   // 16-byte pieces per lane and tile
 
@@ -665,9 +692,9 @@ __device__ __forceinline__ void f1k_tile_fetch(const float2 *__restrict__ g, int
         const int y = i / (F1K_TILE / 2), cp = (i % (F1K_TILE / 2)) * 2;
         q[n] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (c0 + cp + 1 < ncols) {
-            q[n] = *reinterpret_cast<const float4 *>(g + (int64_t)y * hp + c0 + cp);
+            q[n] = *reinterpret_cast<const float4 *>(g + f1k_spec_index(y, c0 + cp));
         } else if (c0 + cp < ncols) {
-            const float2 a = g[(int64_t)y * hp + c0 + cp];
+            const float2 a = g[f1k_spec_index(y, c0 + cp)];
             q[n].x = a.x;
             q[n].y = a.y;
         }
@@ -700,17 +727,11 @@ f1k_cols_fused_kernel(float2 *__restrict__ spec_t, const float2 *__restrict__ sp
     float2 *x = tile + wave * F1K_COL;
     for (int i = threadIdx.x; i < F1K; i += 64 * F1K_TILE)
         twiddle[i] = twiddle_table[i];
-    // Neighbouring tiles share every 128-byte line of a spectrum row.  Workgroups
-    // b, b + 8, b + 16, ... run on the same XCD (round-robin dispatch), so they are given
-    // neighbouring work items: the later ones find the lines in that XCD's L2.
     int first = blockIdx.x;
-    if (F1K_TILE == 8) {
-        if (first < (int)(gridDim.x & ~15u))
-            first = (first & ~15) + ((first & 7) << 1) + ((first >> 3) & 1);
-    } else {
-        if (first < (int)(gridDim.x & ~31u))
-            first = (first & ~31) + ((first & 7) << 2) + ((first >> 3) & 3);
-    }
+#ifdef SV_F1K_REMAP
+    if (first < (int)(gridDim.x & ~31u))
+        first = (first & ~31) + ((first & 7) << 2) + ((first >> 3) & 3);
+#endif
 
     float4 q[F1K_QUADS];
     int item = first;
@@ -762,9 +783,9 @@ f1k_cols_fused_kernel(float2 *__restrict__ spec_t, const float2 *__restrict__ sp
             const int y = i / (F1K_TILE / 2), cp = (i % (F1K_TILE / 2)) * 2;
             const float2 a = tile[cp * F1K_COL + f1k_idx(y)], b = tile[(cp + 1) * F1K_COL + f1k_idx(y)];
             if (c0 + cp + 1 < ncols)
-                *reinterpret_cast<float4 *>(gt + (int64_t)y * hp + c0 + cp) = make_float4(a.x, a.y, b.x, b.y);
+                *reinterpret_cast<float4 *>(gt + f1k_spec_index(y, c0 + cp)) = make_float4(a.x, a.y, b.x, b.y);
             else if (c0 + cp < ncols)
-                gt[(int64_t)y * hp + c0 + cp] = a;
+                gt[f1k_spec_index(y, c0 + cp)] = a;
         }
         __syncthreads();                               // LDS is rewritten by the next item
     }
@@ -811,13 +832,13 @@ f1k_rows_inverse_kernel(const float2 *__restrict__ spec, const float *__restrict
         }
         return;
     }
-    const float2 *p0 = spec + ((int64_t)pair * H + y0) * hp;
-    const float2 *p1 = second ? p0 + hp : p0;
+    const float2 *p0 = spec + (int64_t)pair * H * hp + f1k_spec_index(y0, 0);
+    const float2 *p1 = second ? p0 + 4 : p0;        // the next row of every column group
 #pragma unroll
     for (int i = 0; i <= 8; ++i) {
         const int k = lane + 64 * i;
         if (k <= F1K / 2) {
-            const float2 a = p0[k], b = p1[k];
+            const float2 a = p0[f1k_spec_index(0, k)], b = p1[f1k_spec_index(0, k)];
             x[f1k_idx(digit_reverse(k, 10))] = make_float2(a.x - b.y, a.y + b.x);          // a + i b
             if (k > 0 && k < F1K / 2)       // Hermitian completion: conj(a) + i conj(b)
                 x[f1k_idx(digit_reverse(F1K - k, 10))] = make_float2(a.x + b.y, b.x - a.y);
