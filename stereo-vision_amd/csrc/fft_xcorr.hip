@@ -667,9 +667,9 @@ f1k_rows_forward_kernel(const float *__restrict__ t, int th, int tw_, const floa
 // pass 2, H = 1024: a tile of F1K_TILE spectrum columns; wavefront c transforms
 // column c of T (kept in registers), then column c of R, multiplies and transforms
 // back.  The R tile is fetched into registers before the T transform starts, so its
-// memory latency is covered by arithmetic.  Tiles of 4 columns (32-byte row pieces,
-// four workgroups of one XCD share each 128-byte line through its L2) in workgroups
-// of 4 wavefronts measured faster than tiles of 8 in workgroups of 8: the phases
+// memory latency is covered by arithmetic.  A tile is one column group of the
+// spectrum layout (f1k_spec_index): 32 KB of consecutive memory.  Workgroups of 4
+// wavefronts measured faster than tiles of 8 columns in workgroups of 8: the phases
 // of independent small workgroups on a CU overlap where one large workgroup waits
 // at its barriers.
 #ifndef SV_F1K_TILE
@@ -727,11 +727,7 @@ f1k_cols_fused_kernel(float2 *__restrict__ spec_t, const float2 *__restrict__ sp
     float2 *x = tile + wave * F1K_COL;
     for (int i = threadIdx.x; i < F1K; i += 64 * F1K_TILE)
         twiddle[i] = twiddle_table[i];
-    int first = blockIdx.x;
-#ifdef SV_F1K_REMAP
-    if (first < (int)(gridDim.x & ~31u))
-        first = (first & ~31) + ((first & 7) << 2) + ((first >> 3) & 3);
-#endif
+    const int first = blockIdx.x;
 
     float4 q[F1K_QUADS];
     int item = first;
