@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-'''Secondary measurements: the other BASELINE configs (the headline config is
+'''Secondary measurements: the workloads next to the headline one (which is
 bench.py's).  Prints one JSON line per measurement.  GPU times are wall clock of
 the host-level call (upload + kernels + download) unless marked "device".
 
@@ -9,6 +9,7 @@ the host-level call (upload + kernels + download) unless marked "device".
   config 3  sequence_scan with the portal scan config (12x12 windows, 11x1
             scheme) on the 560x790 cone pair and on a synthetic 960x1080 pair
   config 5  batched 1024x1024 circular NCC through the LDS FFT, B = 8 and 64
+  n1-n4     displacement grids, peak finder, image preparation, long 1D search
 '''
 import contextlib
 import io
