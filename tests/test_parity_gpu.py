@@ -822,3 +822,30 @@ def test_driver_image_comparison(mods, tmp_path, monkeypatch, capsys):
     ref = golden('g10_cone_depth_grids')
     for key in ('depth_grid', 'dp_x_grid', 'dp_y_grid', 'contributions_grid'):
         assert np.array_equal(np.array(saved[key]), ref[f'scan_config_{key}']), key
+
+
+def test_driver_image_comparison_downsampled(mods, oracle, tmp_path, monkeypatch, capsys):
+    '''--ds_factor 2: the driver's images go through the device downsample (no
+    scikit-image needed); grids as the oracle's scan of the oracle's downsampled pair
+    paints them.'''
+    from PIL import Image
+    im = golden('g6_cone_images')
+    cfg = [[{'window_width': 30, 'window_height': 30, 'scheme': [7, 1], 'scheme_shift_size': [4, 0],
+             'window_overlap': 0.5, 'correlation_threshold': 0.8}]]
+    Image.fromarray(im['left'], 'L').save(tmp_path / 'left_cone.tiff')
+    Image.fromarray(im['right'], 'L').save(tmp_path / 'right_cone.tiff')
+    (tmp_path / 'cfg.json').write_text(json.dumps(cfg))
+    run_driver('test_image_comparison',
+               ['--images', 'cone', '--config', 'cfg.json', '--ds_factor', '2', '--hide_depth', '--depth_output',
+                'depth.json', '--image_dir', str(tmp_path), '--config_dir', str(tmp_path), '--data_dir', str(tmp_path)],
+               monkeypatch, capsys)
+    saved = json.loads((tmp_path / 'depth.json').read_text())
+    shape = (im['left'].shape[0] // 2, im['left'].shape[1] // 2)
+    left, right = oracle.downsample(im['left'], 2), oracle.downsample(im['right'], 2)
+    want = oracle.depth_grids([oracle.sequence_scan(left, right, cfg[0])], shape)
+    for got_key, grid in zip(('depth_grid', 'dp_x_grid', 'dp_y_grid', 'contributions_grid'), want):
+        got = np.array(saved[got_key])
+        assert got.shape == shape
+        assert np.array_equal(got, grid), got_key
+    assert np.count_nonzero(np.array(saved['dp_x_grid'])) > 0
+
