@@ -436,11 +436,12 @@ __device__ __forceinline__ void pair_row(pf2 (&acc)[G], const float *__restrict_
     }
 }
 
-// Columns of the row-pair image S that hold data: the padded surface columns, the
-// padded template width and the quads the window prefetch reads ahead.
+// Columns of the row-pair image S that hold data: the last task starts at column
+// gcols - G, walks mwp template columns and its window reads run G + 4 columns ahead
+// (the quads requested in advance), i.e. up to column gcols + mwp + 3.
 __host__ __device__ __forceinline__ int pair_row_cols(int gcols, int mwp)
 {
-    return (gcols + mwp + 12 + 3) & ~3;
+    return (gcols + mwp + 4 + 3) & ~3;
 }
 
 // LDS banks.  A lane reads its window 16 bytes at a time; its neighbour's window
