@@ -11,6 +11,8 @@
 // float64 (scan_pairs_kernel: one workgroup per pair, four surface elements per
 // thread) or in float32 with packed FMAs (scan_pairs_f32_kernel: one wavefront
 // per group of pairs, short float32 runs folded into float64).
+#include <algorithm>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -509,6 +511,35 @@ __device__ __forceinline__ void pair_sum2(double &a, double &b, double *red, int
     }
 }
 
+__device__ __forceinline__ bool pair_desc_ok(const PairDesc &d, int max_side)
+{
+    return !(d.r_h <= 0 || d.r_w <= 0 || d.t_h < 0 || d.t_w < 0 || d.t_h > max_side || d.t_w > max_side ||
+             d.r_h > max_side || d.r_w > max_side);
+}
+
+// A lane's first PAIR_KEEP rows of both boxes (column lx, rows ly, ly + ystep, ...),
+// requested but not yet used: the caller decides when to wait for them.
+__device__ __forceinline__ void pair_request_rows(const double *__restrict__ tbase, const double *__restrict__ rbase,
+                                                  const PairDesc &d, bool ok, int lx, int ly, int ystep,
+                                                  double (&tk)[PAIR_KEEP], double (&rk)[PAIR_KEEP])
+{
+    const bool tcol = ok && lx < (int)d.t_w, rcol = ok && lx < (int)d.r_w;
+    const double *Tl = tbase + d.t_off + lx, *Rl = rbase + d.r_off + lx;
+#pragma unroll
+    for (int j = 0; j < PAIR_KEEP; ++j) {
+        const int y = ly + j * ystep;
+        tk[j] = (tcol && y < (int)d.t_h) ? Tl[y * d.t_pitch] : 0.0;
+        rk[j] = (rcol && y < (int)d.r_h) ? Rl[y * d.r_pitch] : 0.0;
+    }
+}
+
+#ifdef SV_PAIR_STAMPS
+__device__ unsigned long long pair_stamps[8];
+#define PAIR_STAMP(slot) do { const unsigned long long now_ = clock64(); stamp_acc_[slot] += now_ - stamp_; stamp_ = now_; } while (0)
+#else
+#define PAIR_STAMP(slot) do { } while (0)
+#endif
+
 template <int G>
 __global__ void __launch_bounds__(2 * WAVE)
 scan_pairs_f32_kernel(const double *__restrict__ tbase, const double *__restrict__ rbase,
@@ -530,9 +561,20 @@ scan_pairs_f32_kernel(const double *__restrict__ tbase, const double *__restrict
     // staging walks the arrays in sweeps as wide as the largest side (a power of two)
     const int cw_shift = max_side <= 8 ? 3 : max_side <= 16 ? 4 : max_side <= 32 ? 5 : 6;
     const int lx = lane & ((1 << cw_shift) - 1), ly = lane >> cw_shift, ystep = nthr >> cw_shift;
+#ifdef SV_PAIR_STAMPS
+    unsigned long long stamp_acc_[8] = {};
+#endif
 
     for (int64_t base = (int64_t)blockIdx.x * slots; base < npairs; base += (int64_t)gridDim.x * slots) {
         __syncthreads();   // LDS reuse across iterations
+        // The staging phases issue few instructions between long waits; given priority
+        // over the wavefronts that are in their FMA phase they get through quickly
+        // (oldest-first issue would otherwise starve a young wavefront's staging for as
+        // long as an older one's FMA phase lasts), and more wavefronts compute at a time.
+        __builtin_amdgcn_s_setprio(3);
+#ifdef SV_PAIR_STAMPS
+        unsigned long long stamp_ = clock64();
+#endif
         // ---- statistics and staging, one slot after the other, all lanes ----
         for (int s = 0; s < slots; ++s) {
             const int64_t p = base + s;
@@ -543,12 +585,12 @@ scan_pairs_f32_kernel(const double *__restrict__ tbase, const double *__restrict
             }
             const PairDesc d = desc[p];
             const int th = (int)d.t_h, tw = (int)d.t_w, rh = (int)d.r_h, rw = (int)d.r_w;
-            if (rh <= 0 || rw <= 0 || th < 0 || tw < 0 || th > max_side || tw > max_side || rh > max_side ||
-                rw > max_side) {
+            if (!pair_desc_ok(d, max_side)) {
                 if (lane == 0)
                     info[s].state = 2;
                 continue;
             }
+            PAIR_STAMP(6);      // descriptor read
             const double *T = tbase + d.t_off;
             const double *R = rbase + d.r_off;
             const int tn = th * tw, rn = rh * rw;
@@ -561,6 +603,7 @@ scan_pairs_f32_kernel(const double *__restrict__ tbase, const double *__restrict
             // of the wavefront walks the same number of rows and column groups.
             for (int i = lane; i < t_floats; i += nthr)
                 Ts[i] = 0.0f;
+            PAIR_STAMP(7);      // template slot zeroed
             // The arrays are walked as sweeps of `ystep` rows: a lane keeps its column lx and
             // visits rows ly, ly + ystep, ...  The first PAIR_KEEP rows of a lane stay in
             // registers between the two passes (all of them for sides up to 32 with two
@@ -568,13 +611,11 @@ scan_pairs_f32_kernel(const double *__restrict__ tbase, const double *__restrict
             double tk[PAIR_KEEP], rk[PAIR_KEEP];
             const bool tcol = lx < tw, rcol = lx < rw;
             const double *Tl = T + lx, *Rl = R + lx;
+            pair_request_rows(tbase, rbase, d, true, lx, ly, ystep, tk, rk);
             // pass 1: means
             double ts = 0.0, rs = 0.0;
 #pragma unroll
             for (int j = 0; j < PAIR_KEEP; ++j) {
-                const int y = ly + j * ystep;
-                tk[j] = (tcol && y < th) ? Tl[y * d.t_pitch] : 0.0;
-                rk[j] = (rcol && y < rh) ? Rl[y * d.r_pitch] : 0.0;
                 ts += tk[j];
                 rs += rk[j];
             }
@@ -584,7 +625,9 @@ scan_pairs_f32_kernel(const double *__restrict__ tbase, const double *__restrict
                 if (rcol && y < rh)
                     rs += Rl[y * d.r_pitch];
             }
+            PAIR_STAMP(0);      // first pass: rows arrived and summed
             pair_sum2(ts, rs, red, nthr);
+            PAIR_STAMP(1);      // loads arrived, means reduced
             const double tmean = ts / (double)tn, rmean = rs / (double)rn;
             // pass 2: squared deviations; the centred values go to LDS on the way (the
             // reduction in between orders them after the zero fill)
@@ -618,6 +661,7 @@ scan_pairs_f32_kernel(const double *__restrict__ tbase, const double *__restrict
                 }
             }
             pair_sum2(tq, rq, red, nthr);
+            PAIR_STAMP(2);      // deviations, LDS copies
             const double tstd = sqrt(tq / (double)tn), rstd = sqrt(rq / (double)rn);
             const bool flat = tstd < min_std;
             if (lane == 0) {
@@ -645,6 +689,8 @@ scan_pairs_f32_kernel(const double *__restrict__ tbase, const double *__restrict
             }
         }
         __syncthreads();
+        PAIR_STAMP(3);          // row-pair image
+        __builtin_amdgcn_s_setprio(0);
 
         // ---- the surfaces: lane -> (slot, task) ----
         // Loop bounds are made wave-uniform (the largest row / column-group / task
@@ -741,6 +787,8 @@ scan_pairs_f32_kernel(const double *__restrict__ tbase, const double *__restrict
                 }
             }
         }
+        PAIR_STAMP(4);          // surfaces
+        __builtin_amdgcn_s_setprio(3);
         // ---- per-slot results ----
         for (int s = 0; s < slots; ++s) {
             const int state = info[s].state;
@@ -778,7 +826,13 @@ scan_pairs_f32_kernel(const double *__restrict__ tbase, const double *__restrict
                     out_argmax[p] = -1;
             }
         }
+        PAIR_STAMP(5);          // maxima
     }
+#ifdef SV_PAIR_STAMPS
+    if (threadIdx.x == 0)
+        for (int i = 0; i < 8; ++i)
+            atomicAdd(&pair_stamps[i], stamp_acc_[i]);
+#endif
 }
 
 // image_scan's sequential selection rule, one thread per window.
@@ -916,3 +970,14 @@ extern "C" int svamd_scan_fold(const double *corr_max, const uint8_t *is_centre,
     SV_LAUNCH_CHECK();
     return SVAMD_OK;
 }
+
+#ifdef SV_PAIR_STAMPS
+extern "C" int svamd_debug_pair_stamps(unsigned long long *out8, int reset)
+{
+    if (reset) {
+        unsigned long long zero[8] = {};
+        return hipMemcpyToSymbol(HIP_SYMBOL(pair_stamps), zero, sizeof(zero)) == hipSuccess ? 0 : 4;
+    }
+    return hipMemcpyFromSymbol(out8, HIP_SYMBOL(pair_stamps), 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : 4;
+}
+#endif
