@@ -678,7 +678,15 @@ scan_pairs_f32_kernel(const double *__restrict__ tbase, const double *__restrict
             if (flat)
                 continue;
             // S[a][x] = (r'[a][x mod rw], r'[(a + 1) mod rh][x mod rw]) from the plain copy
-            for (int x = lane; x < rcols; x += nthr) {
+            for (int x = lane; x < rxp; x += nthr) {
+                if (x >= rcols) {
+                    // the pitch's padding columns: a lane that shares its wavefront with a wider
+                    // pair walks past its own columns (against template zeros) and must not meet
+                    // whatever bit patterns the LDS held before
+                    for (int a = 0; a < rh; ++a)
+                        *reinterpret_cast<pf2 *>(Ss + 2 * (a * rxp + x)) = pf2{0.f, 0.f};
+                    continue;
+                }
                 const int xs = x % rw;
                 float cur = Ps[xs];
                 for (int a = 0; a < rh; ++a) {
