@@ -367,6 +367,34 @@ def test_scan_pairs_vs_oracle(mods, oracle):
         assert_surface_close(out.cpu().numpy(), want, tol, f'pairs precision {precision}')
 
 
+@pytest.mark.parametrize('max_side', [8, 12, 16, 20, 27])
+def test_scan_pairs_shared_wavefronts_mixed_sizes(mods, oracle, max_side):
+    '''Small pairs share a wavefront (several LDS slots side by side, loop bounds taken
+    from the largest pair of the wavefront): boxes of every size up to max_side in
+    one call, float32 and float64 accumulation against the oracle.'''
+    import torch
+    nv = mods['n']
+    rng = np.random.default_rng(max_side)
+    H, W = 48, 80
+    left, right = rng.random((H, W)), rng.random((H, W))
+    boxes = []
+    for _ in range(400):
+        th, tw, rh, rw = rng.integers(1, max_side + 1, size=4)
+        ty, tx = rng.integers(0, H - th + 1), rng.integers(0, W - tw + 1)
+        ry, rx = rng.integers(0, H - rh + 1), rng.integers(0, W - rw + 1)
+        boxes.append((ty * W + tx, W, th, tw, ry * W + rx, W, rh, rw))
+    desc = np.array(boxes, dtype=np.int64)
+    want = np.array([oracle.cross_correlate_2d_spectral(
+        left[d[0] // W:d[0] // W + d[2], d[0] % W:d[0] % W + d[3]],
+        right[d[4] // W:d[4] // W + d[6], d[4] % W:d[4] % W + d[7]], want='max') for d in desc])
+    dl, dr, dd = nv.to_device(left), nv.to_device(right), nv.to_device(desc)
+    for precision, tol in ((nv.ACC_F32, SURFACE_TOL), (nv.ACC_F64, 1e-11)):
+        out = nv.empty(len(desc), torch.float64)
+        nv.call('svamd_scan_pairs', nv.ptr(dl), nv.ptr(dr), nv.ptr(dd), len(desc), max_side, 1e-4, 1e-9,
+                precision, nv.ptr(out), None, None, None, nv.stream_ptr())
+        assert_surface_close(out.cpu().numpy(), want, tol, f'pairs up to {max_side}, precision {precision}')
+
+
 # ---- dense band scan ---------------------------------------------------------------
 def synthetic_pair(h, w, seed, max_shift):
     rng = np.random.default_rng(seed)
