@@ -96,20 +96,44 @@ __device__ __forceinline__ void block_sum2(double &a, double &b, double *red)
     }
 }
 
-// Row pitch (in elements) of the float64 kernel's wrapped region image.  A lane reads
-// its window 16 bytes at a time and its neighbour's window starts 32 bytes further
-// on, so the lanes of one surface row touch every other 16-byte slot; the 16-lane
-// groups of a 16-byte LDS read ({0-3, 12-15, 20-27}, ...) span four consecutive rows.
-// A pitch of 16 mod 32 elements (128 mod 256 bytes) puts the second half of row
-// k + 1 on the banks the first half of row k leaves free, and odd rows are stored
-// with the two slots of every 32 bytes exchanged: together a group covers all banks.
+// Row pitch (in elements) of the float64 kernel's wrapped region image, for tasks of
+// W surface columns.  A lane reads its window 16 bytes at a time and its neighbour's
+// window starts 8 W bytes further on, so the lanes of one surface row touch every
+// other (W = 4) or every fourth (W = 8) 16-byte slot; the 16-lane groups of a 16-byte
+// LDS read ({0-3, 12-15, 20-27}, ...) span several consecutive rows.  W = 4: a pitch of
+// 16 mod 32 elements puts the second half of row k + 1 on the banks the first half of
+// row k leaves free, and odd rows are stored with the two slots of every 32 bytes
+// exchanged.  W = 8: a pitch of 2 mod 4 elements moves each of a group's four rows
+// onto its own quarter of the slots.  Either way a group covers all 64 banks.
+template <int W>
 __host__ __device__ __forceinline__ int pair64_row_pitch(int rw, int mwp)
 {
-    const int c = (rw + mwp + 4 + 3) & ~3;
-    return ((c + 15) & ~31) + 16;
+    const int c = ((rw + W - 1) / W * W + mwp + 3) & ~3;       // columns the window reads reach
+    return W == 4 ? ((c + 15) & ~31) + 16 : c + 2;
 }
 
-template <typename CT>
+// One step of the float64 task loop: four template columns against the lane's window
+// of W + 3 region values.  The window lives in a ring of W + 4 registers whose base
+// B advances by 4 per step (whole rotations are unrolled by the caller).
+template <int W, int B>
+__device__ __forceinline__ void pair64_step(double (&part)[W], double (&win)[W + 4], const double *__restrict__ trow,
+                                            const double *__restrict__ rrow, int n0, int sw)
+{
+    constexpr int R = W + 4;
+    double tv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        tv[j] = trow[n0 + j];
+        win[(B + W + j) % R] = rrow[n0 + W + (j ^ sw)];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < W; ++j)
+            part[j] = fma(tv[i], win[(B + i + j) % R], part[j]);
+}
+
+template <typename CT, int W>
 __global__ void __launch_bounds__(256)
 scan_pairs_kernel(const double *__restrict__ tbase, const double *__restrict__ rbase,
                   const PairDesc *__restrict__ desc, int64_t npairs, int max_side, double min_std,
@@ -148,7 +172,7 @@ scan_pairs_kernel(const double *__restrict__ tbase, const double *__restrict__ r
         const int mh = min(th, rh), mw = min(tw, rw);
         const int mwp = (mw + 3) & ~3;
         static_assert(sizeof(CT) == 8, "the bank layout below is for 8-byte elements");
-        const int rxp = pair64_row_pitch(rw, mwp);
+        const int rxp = pair64_row_pitch<W>(rw, mwp);
         CT *Rx = Tb + mh * mwp;
         for (int i = threadIdx.x; i < rh * rxp; i += blockDim.x)
             Rx[i] = CT(0);
@@ -188,7 +212,7 @@ scan_pairs_kernel(const double *__restrict__ tbase, const double *__restrict__ r
             if (rcol && y < rh) {
                 const double v = rval - rmean;
                 rq += v * v;
-                const int sw = (y & 1) << 1;
+                const int sw = W == 4 ? (y & 1) << 1 : 0;
                 Rx[y * rxp + (lx ^ sw)] = (CT)v;
                 if (lx < mw - 1)                        // the horizontal wrap
                     Rx[y * rxp + ((lx + rw) ^ sw)] = (CT)v;
@@ -222,51 +246,61 @@ scan_pairs_kernel(const double *__restrict__ tbase, const double *__restrict__ r
         // wherever the normalised region is finite.
         const double scale = tn == 0 ? ((rstd > 0.0) ? 0.0 : NAN) : 1.0 / (tstd * (double)tn) / rstd;
 
-        // One task = 4 horizontally adjacent surface elements (k, l0 .. l0+3): the
-        // region row is walked with a sliding 8-value register window, so every
-        // 4-wide LDS read of template and region feeds 16 FMAs.
+        // One task = W horizontally adjacent surface elements (k, l0 .. l0 + W - 1): the
+        // region row is walked with a sliding register window, so every four 16-byte LDS
+        // reads (two of template, two of region) feed 4 W FMAs.
         BestNan mine;
         mine.best = -INFINITY;
         mine.arg = 0x7fffffff;
         mine.has_nan = 0;
-        const int lgroups = (rw + 3) / 4;
+        const int lgroups = (rw + W - 1) / W;
         for (int task = threadIdx.x; task < rh * lgroups; task += blockDim.x) {
-            const int k = task / lgroups, l0 = (task - k * lgroups) * 4;
-            double acc[4] = {0.0, 0.0, 0.0, 0.0};
+            const int k = task / lgroups, l0 = (task - k * lgroups) * W;
+            double acc[W];
+#pragma unroll
+            for (int j = 0; j < W; ++j)
+                acc[j] = 0.0;
             for (int m = 0; m < mh; ++m) {
                 int rr = m + k;
                 if (rr >= rh)
                     rr -= rh;
                 const CT *trow = Tb + m * mwp;
                 const CT *rrow = Rx + rr * rxp + l0;
-                const int sw = (rr & 1) << 1;       // odd rows: 16-byte slots exchanged in pairs
-                CT part[4] = {CT(0), CT(0), CT(0), CT(0)};
-                CT win[8];
+                const int sw = W == 4 ? (rr & 1) << 1 : 0;   // W = 4: odd rows have their slots exchanged in pairs
+                double part[W], win[W + 4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < W; ++j) {
+                    part[j] = 0.0;
                     win[j] = rrow[j ^ sw];
-                for (int n0 = 0; n0 < mwp; n0 += 4) {
-                    CT tv[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        tv[j] = trow[n0 + j];
-                        win[4 + j] = rrow[n0 + 4 + (j ^ sw)];
+                }
+                // whole rotations of the window ring in the loop: every register is back in
+                // its role at the loop's end
+                int n0 = 0;
+                if constexpr (W == 4) {
+                    for (; n0 + 8 <= mwp; n0 += 8) {
+                        pair64_step<W, 0>(part, win, trow, rrow, n0, sw);
+                        pair64_step<W, 4>(part, win, trow, rrow, n0 + 4, sw);
                     }
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            part[j] = fma(tv[i], win[i + j], part[j]);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        win[j] = win[4 + j];
+                    if (n0 < mwp)
+                        pair64_step<W, 0>(part, win, trow, rrow, n0, sw);
+                } else {
+                    for (; n0 + 12 <= mwp; n0 += 12) {
+                        pair64_step<W, 0>(part, win, trow, rrow, n0, sw);
+                        pair64_step<W, 4>(part, win, trow, rrow, n0 + 4, sw);
+                        pair64_step<W, 8>(part, win, trow, rrow, n0 + 8, sw);
+                    }
+                    if (n0 < mwp) {
+                        pair64_step<W, 0>(part, win, trow, rrow, n0, sw);
+                        if (n0 + 4 < mwp)
+                            pair64_step<W, 4>(part, win, trow, rrow, n0 + 4, sw);
+                    }
                 }
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[j] += (double)part[j];
+                for (int j = 0; j < W; ++j)
+                    acc[j] += part[j];
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < W; ++j) {
                 if (l0 + j >= rw)
                     continue;
                 const int idx = k * rw + l0 + j;
@@ -896,9 +930,13 @@ extern "C" int svamd_scan_pairs(const double *tbase, const double *rbase, const 
                "scan_pairs: unknown accumulation precision %d", acc_precision);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const size_t side4 = ((size_t)max_side + 3) & ~(size_t)3;
-    const size_t elems = (size_t)max_side * side4 + (size_t)max_side * pair64_row_pitch(max_side, (int)side4);
-    // one task per 4 surface elements of a row: small windows get small workgroups
-    const int tasks = max_side * ((max_side + 3) / 4);
+    // float64 kernel: tasks of 8 surface columns from 16 columns on (half the LDS reads per FMA), else of 4
+    const int w64 = max_side >= 16 ? 8 : 4;
+    const size_t elems = (size_t)max_side * side4 +
+                         (size_t)max_side * (w64 == 8 ? pair64_row_pitch<8>(max_side, (int)side4)
+                                                      : pair64_row_pitch<4>(max_side, (int)side4));
+    // small windows get small workgroups
+    const int tasks = max_side * ((max_side + w64 - 1) / w64);
     const int threads = tasks <= 64 ? 64 : tasks <= 128 ? 128 : 256;
     const unsigned grid = (unsigned)(npairs < (1 << 20) ? npairs : (1 << 20));
     const PairDesc *pd = reinterpret_cast<const PairDesc *>(desc);
@@ -946,17 +984,24 @@ extern "C" int svamd_scan_pairs(const double *tbase, const double *rbase, const 
         }
     } else {
         const size_t lds = elems * sizeof(double);
-        if (lds > 64 * 1024) {
-            static bool raised = false;  // attribute is per function, sticky
-            if (!raised) {
-                SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_pairs_kernel<double>),
+        static bool raised4 = false, raised8 = false;   // the attribute is per function, sticky
+        if (w64 == 8) {
+            if (lds > 64 * 1024 && !raised8) {
+                SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_pairs_kernel<double, 8>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-                raised = true;
+                raised8 = true;
             }
+            hipLaunchKernelGGL((scan_pairs_kernel<double, 8>), dim3(grid), dim3(threads), lds, st, tbase, rbase, pd,
+                               npairs, max_side, min_std, min_mean_diff, out_max, out_argmax, surfaces, surf_off);
+        } else {
+            if (lds > 64 * 1024 && !raised4) {
+                SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_pairs_kernel<double, 4>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+                raised4 = true;
+            }
+            hipLaunchKernelGGL((scan_pairs_kernel<double, 4>), dim3(grid), dim3(threads), lds, st, tbase, rbase, pd,
+                               npairs, max_side, min_std, min_mean_diff, out_max, out_argmax, surfaces, surf_off);
         }
-        hipLaunchKernelGGL((scan_pairs_kernel<double>), dim3(grid), dim3(threads), lds, st, tbase, rbase, pd,
-                           npairs, max_side, min_std, min_mean_diff, out_max, out_argmax, surfaces,
-                           surf_off);
     }
     SV_LAUNCH_CHECK();
     return SVAMD_OK;
