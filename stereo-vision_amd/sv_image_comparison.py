@@ -189,33 +189,31 @@ def _stage0_windows(template_image, region_image, x_window, y_window, scheme, sc
     ay = _axis_candidates(ys, y_window, y_span_hw, scheme[1], image_height)
     size = (x_window, y_window)
 
+    # per window column / row: the candidates that survive clipping, as tuples
+    # (centre, begin, end, is the window's own centre)
+    x_cands = [[(g, b, e, g == c) for g, b, e, rej in zip(grid, begin, end, rejected) if not rej]
+               for c, grid, begin, end, rejected in zip(ax['centres'], ax['grid'], ax['begin'], ax['end'],
+                                                        ax['rejected'])]
+    y_cands = [[(g, b, e, g == c) for g, b, e, rej in zip(grid, begin, end, rejected) if not rej]
+               for c, grid, begin, end, rejected in zip(ay['centres'], ay['grid'], ay['begin'], ay['end'],
+                                                        ay['rejected'])]
+    x_own = list(zip(ax['own_rejected'], ax['own_begin'], ax['own_end'], ax['centres']))
+    y_own = list(zip(ay['own_rejected'], ay['own_begin'], ay['own_end'], ay['centres']))
     windows = {}
     window_id = 0
     for row, y in enumerate(ys.tolist()):
-        y_centre = ay['centres'][row]
-        y_grid, y_rej = ay['grid'][row], ay['rejected'][row]
-        y_begin, y_end = ay['begin'][row], ay['end'][row]
+        y_rej, oy0, oy1, y_centre = y_own[row]
+        y_cand = y_cands[row]
         for column, x in enumerate(xs.tolist()):
-            x_centre = ax['centres'][column]
-            x_grid, x_rej = ax['grid'][column], ax['rejected'][column]
-            x_begin, x_end = ax['begin'][column], ax['end'][column]
+            x_rej, ox0, ox1, x_centre = x_own[column]
             centre = (x_centre, y_centre)
-            regions = []
             # the window's own position first, then the scheme grid row by row
-            if not (ax['own_rejected'][column] or ay['own_rejected'][row]):
-                x0, x1 = ax['own_begin'][column], ax['own_end'][column]
-                y0, y1 = ay['own_begin'][row], ay['own_end'][row]
-                regions.append({'centre': centre, 'size': (x1 - x0, y1 - y0),
-                                'image_slice': region_image[y0:y1, x0:x1]})
-            for j, _y in enumerate(y_grid):
-                at_row = _y == y_centre
-                y0, y1 = y_begin[j], y_end[j]
-                for i, _x in enumerate(x_grid):
-                    if (at_row and _x == x_centre) or x_rej[i] or y_rej[j]:
-                        continue
-                    x0, x1 = x_begin[i], x_end[i]
-                    regions.append({'centre': (_x, _y), 'size': (x1 - x0, y1 - y0),
-                                    'image_slice': region_image[y0:y1, x0:x1]})
+            regions = [] if (x_rej or y_rej) else [{'centre': centre, 'size': (ox1 - ox0, oy1 - oy0),
+                                                    'image_slice': region_image[oy0:oy1, ox0:ox1]}]
+            regions += [{'centre': (_x, _y), 'size': (x1 - x0, y1 - y0), 'image_slice': region_image[y0:y1, x0:x1]}
+                        for _y, y0, y1, at_row in y_cand
+                        for _x, x0, x1, at_column in x_cands[column]
+                        if not (at_row and at_column)]
             windows[window_id] = {
                 'row': row,
                 'column': column,
