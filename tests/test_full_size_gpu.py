@@ -1,0 +1,214 @@
+'''Parity at the benchmark's full sizes, where the oracle cannot run the whole
+workload in seconds: sampled slices against the oracle, and properties that do not
+depend on the size (planted disparities, determinism, sharding, shifts, direct dot
+products at sampled output positions).  GPU only; everything goes through the C ABI.
+'''
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import ROOT, assert_surface_close
+
+pytestmark = pytest.mark.gpu
+
+sys.path.insert(0, ROOT)
+
+WIN, MAX_DISP, THRESHOLD = 31, 128, 0.5
+
+
+@pytest.fixture(scope='module')
+def dense():
+    '''The benchmark's own 4096 x 4096 pair, scanned once in each mode.'''
+    import band_scan as bs
+    import bench
+    left, right = bench.synthetic_pair(4096, 4096, seed=1000)
+    scanner = bs.BandScanner(4096, 4096, WIN, WIN, MAX_DISP)
+    scanner.upload(left, right)
+    scanner.run(THRESHOLD)
+    fold = (scanner.disp.cpu().numpy().copy(), scanner.val.cpu().numpy().copy())
+    scanner.run(None)
+    argmax = (scanner.disp.cpu().numpy().copy(), scanner.val.cpu().numpy().copy())
+    return dict(left=left, right=right, scanner=scanner, fold=fold, argmax=argmax)
+
+
+@pytest.mark.parametrize('row0', [0, 2017, 4066 - 6])
+def test_dense_scan_bands_match_the_oracle(dense, oracle, row0):
+    '''Six window rows at the top, in the middle and at the bottom of the 4096 x
+    4096 scan against the oracle's scan of the image rows those windows cover:
+    disparities exactly, correlations to 1e-12.'''
+    rows = 6
+    crop = slice(row0, row0 + rows + WIN - 1)
+    for mode, key, thr in (('fold', 'fold', THRESHOLD), ('argmax', 'argmax', 0.0)):
+        odisp, oval = oracle.band_scan(dense['left'][crop], dense['right'][crop], WIN, WIN, MAX_DISP, mode=mode,
+                                       threshold=thr)
+        disp, val = dense[key]
+        assert np.array_equal(disp[row0:row0 + rows], odisp), mode
+        assert_surface_close(val[row0:row0 + rows], oval, 1e-12, f'band values, {mode}')
+
+
+def test_dense_scan_recovers_planted_disparities(dense):
+    '''bench.synthetic_pair displaces 256-pixel tiles of the right image by a
+    constant each (right[x] = left[x - d] plus noise of +-2 grey levels).  A window
+    whose box at offset d lies inside the tile displaced by d has an exact match there
+    (near a tile border two tiles can offer one each); the scan must pick one of them.'''
+    rng = np.random.default_rng(1000)
+    # replay the generator's draws: base image first, then one integer per tile
+    rng.integers(0, 256, size=(4096, 4096 + 256), dtype=np.uint8)
+    disp, val = dense['argmax']
+    nwx = 4096 - WIN + 1
+    columns = np.arange(nwx)
+    hits = total = 0
+    for ty in range(0, 4096, 256):
+        rows = slice(ty, min(ty + 256, 4096) - WIN + 1)
+        block = disp[rows]
+        found = np.zeros(block.shape, dtype=bool)
+        offered = np.zeros(nwx, dtype=bool)
+        for tx in range(0, 4096, 256):
+            d = int(rng.integers(-100, 101))
+            inside = (columns + d >= tx) & (columns + d + WIN <= min(tx + 256, 4096))
+            offered |= inside
+            found[:, inside] |= block[:, inside] == d
+        hits += int(found[:, offered].sum())
+        total += int(offered.sum()) * block.shape[0]
+        assert np.all(val[rows][:, offered] > 0.99)
+    assert total > 10_000_000
+    assert hits == total, (hits, total)
+
+
+def test_dense_scan_is_deterministic_and_shards(dense):
+    scanner = dense['scanner']
+    scanner.run(THRESHOLD)
+    again = scanner.disp.cpu().numpy()
+    assert np.array_equal(again, dense['fold'][0])
+    assert np.array_equal(scanner.val.cpu().numpy(), dense['fold'][1], equal_nan=True)
+    # three bands of window rows, as three ranks would scan them
+    scanner.disp.fill_(-9)
+    nwy = scanner.nwy
+    for begin, end in ((0, 1355), (1355, 2711), (2711, nwy)):
+        scanner.run(THRESHOLD, rows=(begin, end))
+    assert np.array_equal(scanner.disp.cpu().numpy(), dense['fold'][0])
+
+
+def test_dense_scan_selection_rule_follows_from_the_argmax(dense):
+    '''image_scan's rule keeps the centre unless a candidate beats both the
+    threshold and the centre by more than the tolerance: wherever the plain
+    arg-max is below the threshold the rule must report no displacement, and a
+    reported displacement always carries a correlation above the threshold.'''
+    fdisp, fval = dense['fold']
+    adisp, aval = dense['argmax']
+    low = aval < THRESHOLD
+    assert np.all(fdisp[low] == 0)
+    moved = fdisp != 0
+    assert np.all(fval[moved] > THRESHOLD)
+    assert np.all(fval[moved] <= aval[moved] + 1e-15)
+
+
+def test_batched_fft_1024_shift_and_samples(mods_spectral):
+    '''Config 5's shape: 1024 x 1024 pairs through the LDS FFT.  A region that is
+    its template rolled by (dy, dx) peaks there with correlation 1; sampled surface
+    elements equal the direct circular dot product of the reference's formula.'''
+    spec = mods_spectral
+    rng = np.random.default_rng(55)
+    n, batch = 1024, 6
+    templates = rng.random((batch, n, n), dtype=np.float32)
+    shifts = [(0, 0), (1, 1023), (511, 512), (1000, 3), (17, 700), (640, 640)]
+    regions = np.stack([np.roll(templates[b], s, axis=(0, 1)) for b, s in enumerate(shifts)])
+    regions[5] = rng.random((n, n), dtype=np.float32)            # one unrelated pair
+    out = spec.cross_correlate_2d_spectral_batched(templates, regions)
+    for b, s in enumerate(shifts[:5]):
+        peak = np.unravel_index(np.argmax(out[b]), out[b].shape)
+        assert tuple(int(v) for v in peak) == s
+        assert abs(float(out[b][peak]) - 1.0) < 1e-5
+    # direct evaluation at sampled positions (float64 on the host)
+    for b in (2, 5):
+        t = templates[b].astype(np.float64)
+        r = regions[b].astype(np.float64)
+        tn = (t - t.mean()) / (t.std() * t.size)
+        rn = (r - r.mean()) / r.std()
+        for _ in range(12):
+            k, l = (int(v) for v in rng.integers(0, n, size=2))
+            want = float(np.sum(tn * np.roll(rn, (-k, -l), axis=(0, 1))))
+            assert abs(float(out[b, k, l]) - want) <= 1e-5 * max(1.0, abs(want)), (b, k, l)
+
+
+@pytest.fixture(scope='module')
+def mods_spectral():
+    import correlation_spectral
+    import _native
+    _native.torch_cuda()
+    return correlation_spectral
+
+
+def test_million_pairs_sampled_against_the_oracle(oracle):
+    '''2^20 circular 31 x 31 pairs in one call (the reference-faithful dense-scan
+    arithmetic): a pair of identical boxes peaks at 1 at index 0, a random sample
+    of the rest matches the oracle in both accumulation precisions.'''
+    import torch
+    import _native as nv
+    rng = np.random.default_rng(4)
+    H = W = 1024
+    left = rng.random((H, W))
+    right = np.roll(left, 7, axis=1) + 0.01 * rng.random((H, W))
+    n = 1 << 20
+    ty = rng.integers(0, H - 31, size=n)
+    tx = rng.integers(128, W - 31 - 128, size=n)
+    dx = rng.integers(-128, 129, size=n)
+    desc = np.empty((n, 8), dtype=np.int64)
+    desc[:, 0] = ty * W + tx
+    desc[:, 4] = ty * W + tx + dx
+    desc[:, 1] = desc[:, 5] = W
+    desc[:, 2] = desc[:, 3] = desc[:, 6] = desc[:, 7] = 31
+    dl, dr, dd = nv.to_device(left), nv.to_device(right), nv.to_device(desc)
+    sample = rng.integers(0, n, size=150)
+    want = np.array([oracle.cross_correlate_2d_spectral(
+        left[ty[p]:ty[p] + 31, tx[p]:tx[p] + 31],
+        right[ty[p]:ty[p] + 31, tx[p] + dx[p]:tx[p] + dx[p] + 31], want='max') for p in sample])
+    for precision, tol in ((nv.ACC_F32, 1e-5), (nv.ACC_F64, 1e-11)):
+        out = nv.empty(n, torch.float64)
+        arg = nv.empty(n, torch.int64)
+        nv.call('svamd_scan_pairs', nv.ptr(dl), nv.ptr(dr), nv.ptr(dd), n, 31, 1e-4, 1e-9, precision,
+                nv.ptr(out), nv.ptr(arg), None, None, nv.stream_ptr())
+        got = out.cpu().numpy()
+        assert_surface_close(got[sample], want, tol, f'sampled pairs, precision {precision}')
+        assert np.all(np.isfinite(got)) and got.max() <= 1.0 + 1e-6
+        # the planted shift: regions displaced by exactly 7 columns hold the template itself
+        same = np.nonzero(dx == 7)[0]
+        assert len(same) > 1000
+        assert np.all(got[same] > 0.99)
+        assert np.all(arg.cpu().numpy()[same] == 0)
+    # identical boxes
+    desc_same = desc[:4096].copy()
+    desc_same[:, 4] = desc_same[:, 0]
+    d2 = nv.to_device(desc_same)
+    out = nv.empty(4096, torch.float64)
+    arg = nv.empty(4096, torch.int64)
+    nv.call('svamd_scan_pairs', nv.ptr(dl), nv.ptr(dl), nv.ptr(d2), 4096, 31, 1e-4, 1e-9, nv.ACC_F32, nv.ptr(out),
+            nv.ptr(arg), None, None, nv.stream_ptr())
+    assert np.all(np.abs(out.cpu().numpy() - 1.0) < 1e-5) and np.all(arg.cpu().numpy() == 0)
+
+
+def test_long_1d_correlation_sampled(oracle):
+    '''Config 2's length (n = 44 000, 2n - 1 lags): sampled lags against the
+    reference's formula evaluated directly (correlation.py:63-70: the second vector
+    padded with n - 1 zeros either side, both means removed, divided by n), the
+    maximum where the planted delay puts it.'''
+    import contextlib
+    import io
+    import correlation
+    rng = np.random.default_rng(2)
+    n, delay = 44000, 137
+    a = rng.standard_normal(n)
+    b = np.roll(a, delay) + 0.05 * rng.standard_normal(n)
+    with contextlib.redirect_stdout(io.StringIO()):
+        got = correlation.cross_correlate_1d(a, b)
+        short = correlation.cross_correlate_1d(a[:500], b[:500], normalised=True)
+    assert_surface_close(short, oracle.cross_correlate_1d(a[:500], b[:500], normalised=True), 1e-5, 'short 1D')
+    assert got.shape == (2 * n - 1,)
+    assert int(np.argmax(got)) == n - 1 + delay
+    scale = float(np.max(np.abs(got)))
+    padded = np.concatenate([np.zeros(n - 1), b, np.zeros(n - 1)])
+    a0 = a - a.mean()
+    for i in rng.integers(0, 2 * n - 1, size=40):
+        want = float(np.sum(a0 * (padded[i:i + n] - b.mean())) / n)
+        assert abs(float(got[i]) - want) <= 1e-5 * scale, int(i)
