@@ -26,7 +26,10 @@ def as_uint8_image(image):
         return np.ascontiguousarray(image)
     if image.dtype.kind == 'f':
         q = np.rint(image * 255.0)
-        if q.min() >= 0 and q.max() <= 255 and np.array_equal(q / 255.0, image):
+        # 8-bit levels scaled either way: value / 255 or value * (1 / 255), which is
+        # what `utils.downsample(image, 1)` (scikit-image's float conversion) yields
+        if q.min() >= 0 and q.max() <= 255 and (np.array_equal(q / 255.0, image) or
+                                                 np.array_equal(q * (1.0 / 255), image)):
             return np.ascontiguousarray(q.astype(np.uint8))
     raise TypeError('band_scan needs 8-bit images (uint8, or uint8 / 255 as float)')
 
