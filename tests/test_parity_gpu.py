@@ -430,6 +430,19 @@ def test_band_scan_vs_oracle(mods, oracle, win, h, w, md):
         assert_surface_close(val, oval, 1e-12, 'band fold values')
 
 
+def test_band_scan_takes_the_loaders_output(mods):
+    '''`downsample(image, 1)` scales 8-bit levels by the product with 1 / 255 (not the
+    quotient by 255); the band scan recognises both and scans the same integers.'''
+    left, right = synthetic_pair(60, 150, 77, 6)
+    b, u = mods['b'], mods['u']
+    want = b.band_scan(left, right, 15, 15, 8)
+    for scaled in ((u.downsample(left, 1), u.downsample(right, 1)), (left / 255.0, right / 255.0)):
+        got = b.band_scan(scaled[0], scaled[1], 15, 15, 8)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1], equal_nan=True)
+    with pytest.raises(TypeError):
+        b.band_scan(left / 254.0, right / 254.0, 15, 15, 8)
+
+
 def test_band_scan_row_stride_and_sharding(mods, oracle):
     left, right = synthetic_pair(90, 200, 5, 8)
     b = mods['b']
