@@ -76,6 +76,14 @@ def cross_correlate_2d(template: np.ndarray, region: np.ndarray, step_x=1, step_
 
     torch = nv.torch_cuda()
     reg = nv.as_image(region)
+    # A NaN in the region makes every placement whose snapshot touches it NaN in the
+    # reference (the snapshot's mean and deviation are NaN): the kernel sees zeros
+    # there and the touched placements are marked afterwards.
+    holes = np.isnan(reg) if reg.dtype.kind == 'f' else None
+    if holes is not None and holes.any():
+        reg = np.where(holes, 0, reg)
+    else:
+        holes = None
     d_t = nv.to_device(template.astype(np.float64, copy=False))
     d_r = nv.to_device(reg)
     out = nv.empty((output_rows, output_columns), torch.float64)
@@ -84,5 +92,15 @@ def cross_correlate_2d(template: np.ndarray, region: np.ndarray, step_x=1, step_
     nv.call('svamd_cross_correlate_2d', nv.ptr(d_t), th, tw, nv.ptr(d_r), nv.dtype_code(reg), rh, rw,
             int(step_x), int(step_y), nv.ptr(out), nv.ptr(ws), ws.numel(), nv.stream_ptr())
     result = out.cpu().numpy()
+    if holes is not None:
+        # NaNs per snapshot from the mask's summed-area table (snapshots are cut off at
+        # the region's bottom and right edges)
+        table = np.zeros((rh + 1, rw + 1), dtype=np.int64)
+        table[1:, 1:] = holes.cumsum(axis=0).cumsum(axis=1)
+        y0 = np.arange(output_rows) * step_y
+        x0 = np.arange(output_columns) * step_x
+        y1, x1 = np.minimum(y0 + th, rh), np.minimum(x0 + tw, rw)
+        count = (table[np.ix_(y1, x1)] - table[np.ix_(y0, x1)] - table[np.ix_(y1, x0)] + table[np.ix_(y0, x0)])
+        result[count > 0] = np.nan
     _progress(output_rows, 10)
     return result

@@ -416,6 +416,26 @@ def g11_find_peaks(ref):
     save('g11_find_peaks', **arrays)
 
 
+def g13_spatial_nan_region(ref):
+    '''A float region with NaN pixels (and a template with one): the reference yields
+    NaN for every placement whose snapshot touches a NaN of the region.'''
+    corr = ref[0]
+    rng = np.random.default_rng(13)
+    template = rng.random((9, 7)) * 200
+    template[2, 3] = np.nan
+    region = rng.random((30, 41)) * 255
+    region[5:8, 10:12] = np.nan
+    region[29, 40] = np.nan
+    region[17, 0] = np.nan
+    arrays = dict(template=template, region=region)
+    for tag, (sx, sy) in (('a', (1, 1)), ('b', (3, 2))):
+        with np.errstate(all='ignore'):
+            arrays[f'surface_{tag}'] = quiet(corr.cross_correlate_2d, template, region, sx, sy)
+        arrays[f'step_{tag}'] = np.array([sx, sy])
+        print(f'  g13 {tag}: NaNs {np.isnan(arrays[f"surface_{tag}"]).sum()} of {arrays[f"surface_{tag}"].size}')
+    save('g13_spatial_nan_region', **arrays)
+
+
 def g12_greyscale_with_nan(ref):
     '''The reference's loader on its two RGBA images: decoded pixels in, grey
     levels with NaN for transparent pixels out.'''
@@ -443,6 +463,7 @@ GROUPS = {
     'g10': g10_depth_grids,
     'g11': g11_find_peaks,
     'g12': g12_greyscale_with_nan,
+    'g13': g13_spatial_nan_region,
 }
 
 

@@ -192,6 +192,13 @@ def test_g11_find_peaks(oracle, tag):
     assert np.array_equal(x, g[f'{tag}_x']) and np.array_equal(y, g[f'{tag}_y'])
 
 
+def test_g13_spatial_nan_region(oracle):
+    g = golden('g13_spatial_nan_region')
+    for k in 'ab':
+        sx, sy = (int(v) for v in g[f'step_{k}'])
+        close(oracle.cross_correlate_2d(g['template'], g['region'], sx, sy), g[f'surface_{k}'])
+
+
 # ---- image preparation ---------------------------------------------------------------
 def test_g12_greyscale_with_nan(oracle):
     '''The reference's loader on its own two RGBA images: same grey levels, NaN at

@@ -51,6 +51,19 @@ def test_spatial_prints_reference_progress_lines(mods, capsys):
     assert lines[:3] == ['0 / 25', '10 / 25', '20 / 25']
 
 
+def test_g13_spatial_nan_region(mods):
+    '''NaN pixels in the region: NaN for every placement whose snapshot touches one,
+    the reference's values everywhere else.'''
+    g = golden('g13_spatial_nan_region')
+    for k in 'ab':
+        sx, sy = (int(v) for v in g[f'step_{k}'])
+        out = quiet(mods['c'].cross_correlate_2d, g['template'], g['region'], sx, sy)
+        assert_surface_close(out, g[f'surface_{k}'], SURFACE_TOL, f'g13{k}')
+    # float32 regions take the same route
+    out = quiet(mods['c'].cross_correlate_2d, g['template'], g['region'].astype(np.float32), 1, 1)
+    assert np.array_equal(np.isnan(out), np.isnan(g['surface_a']))
+
+
 def test_g2_spatial_nan_template(mods):
     g = golden('g2_spatial_nan_template')
     for k in 'abc':
