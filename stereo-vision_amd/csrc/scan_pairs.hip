@@ -527,7 +527,7 @@ __device__ __forceinline__ BestNan wave_best(BestNan v)
 }
 
 // Two sums over the workgroup at once (in place): one wavefront needs no LDS round
-// trip, two wavefronts exchange their halves through red[0..3].
+// trip, two or four wavefronts exchange their parts through red[0..7].
 __device__ __forceinline__ void pair_sum2(double &a, double &b, double *red, int nthr)
 {
     a = wave_sum(a);
@@ -542,6 +542,10 @@ __device__ __forceinline__ void pair_sum2(double &a, double &b, double *red, int
         __syncthreads();
         a = red[0] + red[2];
         b = red[1] + red[3];
+        if (nthr > 2 * WAVE) {
+            a += red[4] + red[6];
+            b += red[5] + red[7];
+        }
     }
 }
 
@@ -575,7 +579,7 @@ __device__ unsigned long long pair_stamps[8];
 #endif
 
 template <int G>
-__global__ void __launch_bounds__(2 * WAVE)
+__global__ void __launch_bounds__(4 * WAVE)
 scan_pairs_f32_kernel(const double *__restrict__ tbase, const double *__restrict__ rbase,
                       const PairDesc *__restrict__ desc, int64_t npairs, int max_side, int slots,
                       int tasks_per_slot, int slot_floats, int t_floats, int s_floats, double min_std,
@@ -588,8 +592,8 @@ scan_pairs_f32_kernel(const double *__restrict__ tbase, const double *__restrict
     __shared__ double red_d[4];
     __shared__ int red_i[8];
     float *lds = reinterpret_cast<float *>(smem_raw);
-    // 64 threads when several pairs share the wavefront, 128 (two wavefronts on one
-    // pair) otherwise; `lane` is the thread's index in the workgroup
+    // 64 threads when several pairs share the wavefront, 128 or 256 (two or four
+    // wavefronts on one pair) otherwise; `lane` is the thread's index in the workgroup
     const int lane = threadIdx.x, nthr = blockDim.x;
     const int tstride = (max_side + 3) & ~3;     // template row stride in every slot
     // staging walks the arrays in sweeps as wide as the largest side (a power of two)
@@ -957,7 +961,9 @@ extern "C" int svamd_scan_pairs(const double *tbase, const double *rbase, const 
         const int tasks_per_slot = (max_side + 1) / 2 * (gcols / G);
         int slots = two_waves ? 1 : WAVE / tasks_per_slot;
         if (slots < 1) slots = 1;
-        const int fthreads = two_waves ? 2 * WAVE : WAVE;
+        // four wavefronts when two would need more than one round of tasks: large pairs fill an
+        // LDS slot that leaves room for one or two workgroups per CU
+        const int fthreads = !two_waves ? WAVE : (tasks_per_slot > 2 * WAVE ? 4 * WAVE : 2 * WAVE);
         if (slots > PAIR_MAX_SLOTS) slots = PAIR_MAX_SLOTS;
         const size_t lds = (size_t)slots * slot_floats * sizeof(float);
         const int64_t groups = (npairs + slots - 1) / slots;
