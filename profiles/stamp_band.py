@@ -2,7 +2,6 @@
 '''Progress curves of the band kernel's wavefronts, from a diagnostic build of the
 library (-DSVAMD_BAND_STAMPS): for a few workgroups, when each wavefront finished
 each 8-offset pass.  Usage: python3 profiles/stamp_band.py <libsvamd_stamps.so>'''
-import ctypes
 import os
 import sys
 
