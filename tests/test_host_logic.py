@@ -87,3 +87,32 @@ def test_zero_stride_is_rejected(host_only):
     with pytest.raises(ValueError, match='stride of zero'):
         host_only.whole_image_search_regions(np.zeros((40, 40)), np.zeros((40, 40)), 31, 31, (3, 1), (1, 0),
                                              30 / 31)
+
+
+def test_resident_image_is_a_read_only_array_with_a_twin():
+    '''What the loaders return: an ndarray for every numpy purpose, read-only, whose
+    device twin does not follow slices, copies or arithmetic.'''
+    import utils
+    host = np.arange(12.0).reshape(3, 4)
+    twin = object()                       # stands for the device tensor
+    image = utils.ResidentImage(host, twin)
+    assert isinstance(image, np.ndarray) and image.shape == (3, 4) and image.resident is twin
+    with pytest.raises(ValueError):
+        image[0, 0] = 5.0
+    assert image[1:].resident is None and (image * 2).resident is None
+    editable = np.array(image)
+    editable[0, 0] = 5.0
+    assert type(editable) is np.ndarray and host[0, 0] == 0.0
+    assert np.array_equal(np.asarray(image), host) and float(image.sum()) == 66.0
+
+
+def test_band_scan_input_levels():
+    '''8-bit levels are taken as uint8, as value / 255 and as value * (1 / 255); nothing
+    else is (the band kernel's exactness rests on integer pixels).'''
+    import band_scan
+    levels = np.arange(256, dtype=np.uint8).reshape(16, 16)
+    for image in (levels, levels / 255.0, levels * (1.0 / 255), (levels / 255.0).astype(np.float32)):
+        assert np.array_equal(band_scan.as_uint8_image(image), levels)
+    for bad in (levels / 254.0, levels.astype(np.int32), levels / 255.0 + 1e-9):
+        with pytest.raises(TypeError):
+            band_scan.as_uint8_image(bad)
