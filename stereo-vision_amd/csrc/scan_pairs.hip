@@ -641,6 +641,18 @@ scan_pairs_f32_kernel(const double *__restrict__ tbase, const double *__restrict
             // of the wavefront walks the same number of rows and column groups.
             for (int i = lane; i < t_floats; i += nthr)
                 Ts[i] = 0.0f;
+            // Pairs that share a wavefront walk the wave-uniform row and column-group
+            // counts of the largest of them: a narrower pair's lanes read past its own
+            // row pitch and, on its last row, into rows of the slot it never stages.
+            // Those products meet template zeros, but 0 * NaN is NaN, so nothing a lane
+            // can reach may keep the bit patterns of whatever used the LDS before.  (One
+            // wavefront: its LDS operations complete in order, the staging below lands on
+            // top of this fill.)
+            if (slots > 1) {
+                float4 *Sz = reinterpret_cast<float4 *>(Ss);
+                for (int i = lane; i < s_floats / 4; i += nthr)
+                    Sz[i] = float4{0.f, 0.f, 0.f, 0.f};
+            }
             PAIR_STAMP(7);      // template slot zeroed
             // The arrays are walked as sweeps of `ystep` rows: a lane keeps its column lx and
             // visits rows ly, ly + ystep, ...  The first PAIR_KEEP rows of a lane stay in

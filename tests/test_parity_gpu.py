@@ -408,6 +408,48 @@ def test_scan_pairs_shared_wavefronts_mixed_sizes(mods, oracle, max_side):
         assert_surface_close(out.cpu().numpy(), want, tol, f'pairs up to {max_side}, precision {precision}')
 
 
+@pytest.mark.parametrize('max_side', [12, 16])
+def test_scan_pairs_narrow_pair_after_nan_pairs(mods, max_side):
+    '''A pair clipped to a few columns shares its wavefront with full-size pairs and
+    walks their (wider) column range: what it reads beyond its own staging must be
+    zeros, not what an earlier pair left in the LDS.  A first call fills every slot
+    with NaN pixels; the second call's results must be finite and equal to the
+    float64 kernel's (which gives every pair a workgroup of its own).'''
+    import torch
+    nv = mods['n']
+    rng = np.random.default_rng(5 + max_side)
+    H, W = 64, 64
+    poison = np.full((H, W), np.nan)
+    img_l, img_r = rng.random((H, W)), rng.random((H, W))
+    m = max_side
+    full = (0, W, m, m, 0, W, m, m)
+    ndesc = np.array([full] * 8192, dtype=np.int64)
+    boxes = []
+    for i in range(8192):
+        y, x = int(rng.integers(0, H - m + 1)), int(rng.integers(0, W - m + 1))
+        if i % 4 == 1:      # region clipped to a few columns / rows
+            boxes.append((y * W + x, W, m, m, y * W + W - 4, W, m, 4))
+        elif i % 4 == 2:
+            boxes.append((y * W + x, W, m, m, (H - 3) * W + x, W, 3, m))
+        else:
+            boxes.append((y * W + x, W, m, m, y * W + x, W, m, m))
+    desc = np.array(boxes, dtype=np.int64)
+    dp, dl, dr = nv.to_device(poison), nv.to_device(img_l), nv.to_device(img_r)
+    dn, dd = nv.to_device(ndesc), nv.to_device(desc)
+    outs = {}
+    for precision in (nv.ACC_F32, nv.ACC_F64):
+        junk = nv.empty(len(ndesc), torch.float64)
+        nv.call('svamd_scan_pairs', nv.ptr(dp), nv.ptr(dp), nv.ptr(dn), len(ndesc), max_side, 1e-4, 1e-9,
+                nv.ACC_F32, nv.ptr(junk), None, None, None, nv.stream_ptr())
+        out = nv.empty(len(desc), torch.float64)
+        nv.call('svamd_scan_pairs', nv.ptr(dl), nv.ptr(dr), nv.ptr(dd), len(desc), max_side, 1e-4, 1e-9,
+                precision, nv.ptr(out), None, None, None, nv.stream_ptr())
+        outs[precision] = out.cpu().numpy()
+    assert np.isfinite(outs[nv.ACC_F64]).all()
+    assert np.isfinite(outs[nv.ACC_F32]).all(), 'stale LDS reached a narrow pair'
+    assert_surface_close(outs[nv.ACC_F32], outs[nv.ACC_F64], SURFACE_TOL, 'narrow pairs after NaN pairs')
+
+
 # ---- dense band scan ---------------------------------------------------------------
 def synthetic_pair(h, w, seed, max_shift):
     rng = np.random.default_rng(seed)
