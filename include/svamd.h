@@ -114,6 +114,19 @@ size_t svamd_cross_correlate_1d_workspace_bytes(int64_t n);
 int svamd_cross_correlate_1d(const double *v1, const double *v2, int64_t n, int normalised,
                              double *out, void *workspace, size_t workspace_bytes, void *stream);
 
+/* The same correlation for callers that cannot allocate or pass a workspace
+ * (code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc).  No counterpart in the reference.  The workspace is an array inside
+ * the library's code object (about 18.6 MB per device, held until the process
+ * ends); the call allocates and frees nothing.  n is limited to
+ * SVAMD_XCORR1D_STATIC_MAX_N samples (SVAMD_ERR_LIMIT beyond).  All calls on one
+ * device share that array: calls that overlap in time on one device (different
+ * streams or threads) race; calls on one stream, or on different devices, do
+ * not.  Results equal svamd_cross_correlate_1d's bit for bit. */
+#define SVAMD_XCORR1D_STATIC_MAX_N 65536
+int svamd_cross_correlate_1d_static(const double *v1, const double *v2, int64_t n, int normalised,
+                                    double *out, void *stream);
+
 /* ---- a5: cross_correlate_1d_spectral(template, signal) ------------------------
  * correlation_spectral.py:12-30.  out: ns + nt - 1 float64. */
 size_t svamd_cross_correlate_1d_spectral_workspace_bytes(int64_t nt, int64_t ns);

@@ -44,6 +44,7 @@ PROTOTYPES = {
     'svamd_xcorr2d_fft': (_i, [_vp, _i, _i, _vp, _i, _i, _i, _d, _d, _vp, _i, _vp, _sz, _vp]),
     'svamd_cross_correlate_1d_workspace_bytes': (_sz, [_i64]),
     'svamd_cross_correlate_1d': (_i, [_vp, _vp, _i64, _i, _vp, _vp, _sz, _vp]),
+    'svamd_cross_correlate_1d_static': (_i, [_vp, _vp, _i64, _i, _vp, _vp]),
     'svamd_cross_correlate_1d_spectral_workspace_bytes': (_sz, [_i64, _i64]),
     'svamd_cross_correlate_1d_spectral': (_i, [_vp, _i64, _vp, _i64, _vp, _vp, _sz, _vp]),
     'svamd_scan_pairs': (_i, [_vp, _vp, _vp, _i64, _i, _d, _d, _i, _vp, _vp, _vp, _vp, _vp]),

@@ -6,6 +6,7 @@
 // extended (zero padded or wrapped circularly) so that no index leaves it.  The
 // normalisation is an O(1)-per-output epilogue in float64 fed by summed-area
 // tables (spatial) or global statistics (circular / 1D).
+#include <mutex>
 #include <type_traits>
 
 #include "common.h"
@@ -839,16 +840,11 @@ extern "C" size_t svamd_cross_correlate_1d_workspace_bytes(int64_t n)
            align_up(slide_partial_doubles((int)n, 1, 2 * n - 1) * 8, 256);
 }
 
-extern "C" int svamd_cross_correlate_1d(const double *v1, const double *v2, int64_t n, int normalised,
-                                        double *out, void *workspace, size_t workspace_bytes, void *stream)
+// The launches of cross_correlate_1d over a workspace of at least
+// svamd_cross_correlate_1d_workspace_bytes(n) bytes (arguments already checked).
+static int xcorr1d_enqueue(const double *v1, const double *v2, int64_t n, int normalised, double *out,
+                           void *workspace, hipStream_t st)
 {
-    SV_REQUIRE(v1 && v2 && out, SVAMD_ERR_INVALID, "cross_correlate_1d: NULL pointer");
-    SV_REQUIRE(n > 0 && n < (1LL << 30), SVAMD_ERR_INVALID, "cross_correlate_1d: bad length %lld",
-               (long long)n);
-    SV_REQUIRE(workspace && (reinterpret_cast<uintptr_t>(workspace) & 255) == 0 &&
-                   workspace_bytes >= svamd_cross_correlate_1d_workspace_bytes(n),
-               SVAMD_ERR_WORKSPACE, "cross_correlate_1d: workspace missing, misaligned or too small");
-    hipStream_t st = static_cast<hipStream_t>(stream);
     Carver ws(workspace);
     Stats *s1 = ws.take<Stats>(1);
     Stats *s2 = ws.take<Stats>(1);
@@ -873,6 +869,64 @@ extern "C" int svamd_cross_correlate_1d(const double *v1, const double *v2, int6
                        (double)n, normalised ? 1 : 0, normalised ? 1 : 0, s1, s2);
     SV_LAUNCH_CHECK();
     return SVAMD_OK;
+}
+
+extern "C" int svamd_cross_correlate_1d(const double *v1, const double *v2, int64_t n, int normalised,
+                                        double *out, void *workspace, size_t workspace_bytes, void *stream)
+{
+    SV_REQUIRE(v1 && v2 && out, SVAMD_ERR_INVALID, "cross_correlate_1d: NULL pointer");
+    SV_REQUIRE(n > 0 && n < (1LL << 30), SVAMD_ERR_INVALID, "cross_correlate_1d: bad length %lld",
+               (long long)n);
+    SV_REQUIRE(workspace && (reinterpret_cast<uintptr_t>(workspace) & 255) == 0 &&
+                   workspace_bytes >= svamd_cross_correlate_1d_workspace_bytes(n),
+               SVAMD_ERR_WORKSPACE, "cross_correlate_1d: workspace missing, misaligned or too small");
+    return xcorr1d_enqueue(v1, v2, n, normalised, out, workspace, static_cast<hipStream_t>(stream));
+}
+
+// ---- cross_correlate_1d without a workspace argument and without allocation ------
+// The workspace lives in the code object: every device that loads the library holds
+// its own copy of this array, at its own address, until the process ends.  In host
+// code the array's name is not a device address; the address on the current device
+// comes from hipGetSymbolAddress, once per device.
+constexpr int64_t XCORR1D_STATIC_MAX_N = SVAMD_XCORR1D_STATIC_MAX_N;
+constexpr size_t XCORR1D_STATIC_BYTES = 2 * 256 + 2 * 512 * 8 /* statistics partials */ +
+                                        (size_t)XCORR1D_STATIC_MAX_N * (4 + 12 + 8 + 4) /* operands, slack */ +
+                                        (size_t)16 * 2 * XCORR1D_STATIC_MAX_N * 8 /* partial sums */ + 8 * 256;
+static __device__ __align__(256) unsigned char xcorr1d_scratch[XCORR1D_STATIC_BYTES];
+
+namespace {
+constexpr int MAX_DEVICES = 64;
+std::mutex scratch_mutex;
+void *scratch_ptr[MAX_DEVICES] = {};
+}  // namespace
+
+extern "C" int svamd_cross_correlate_1d_static(const double *v1, const double *v2, int64_t n,
+                                               int normalised, double *out, void *stream)
+{
+    SV_REQUIRE(v1 && v2 && out, SVAMD_ERR_INVALID, "cross_correlate_1d_static: NULL pointer");
+    SV_REQUIRE(n > 0, SVAMD_ERR_INVALID, "cross_correlate_1d_static: bad length %lld", (long long)n);
+    SV_REQUIRE(n <= XCORR1D_STATIC_MAX_N, SVAMD_ERR_LIMIT,
+               "cross_correlate_1d_static: n = %lld exceeds the built-in workspace's limit of %lld samples; "
+               "use svamd_cross_correlate_1d with a workspace",
+               (long long)n, (long long)XCORR1D_STATIC_MAX_N);
+    SV_REQUIRE(svamd_cross_correlate_1d_workspace_bytes(n) <= XCORR1D_STATIC_BYTES, SVAMD_ERR_LIMIT,
+               "cross_correlate_1d_static: built-in workspace too small for n = %lld", (long long)n);
+    int dev = -1;
+    SV_HIP(hipGetDevice(&dev));
+    SV_REQUIRE(dev >= 0 && dev < MAX_DEVICES, SVAMD_ERR_LIMIT, "cross_correlate_1d_static: device index %d", dev);
+    void *ws;
+    {
+        std::lock_guard<std::mutex> lock(scratch_mutex);
+        if (!scratch_ptr[dev]) {
+            void *p = nullptr;
+            SV_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(xcorr1d_scratch)));
+            SV_REQUIRE(p && (reinterpret_cast<uintptr_t>(p) & 255) == 0, SVAMD_ERR_HIP,
+                       "cross_correlate_1d_static: built-in workspace has no usable device address");
+            scratch_ptr[dev] = p;
+        }
+        ws = scratch_ptr[dev];
+    }
+    return xcorr1d_enqueue(v1, v2, n, normalised, out, ws, static_cast<hipStream_t>(stream));
 }
 
 // ================================ a5 ==========================================
