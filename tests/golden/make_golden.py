@@ -436,6 +436,48 @@ def g13_spatial_nan_region(ref):
     save('g13_spatial_nan_region', **arrays)
 
 
+def g14_dense_spatial_fold(ref):
+    '''The reference's own selection rule (sv_image_comparison.py:236-255) over the
+    SPATIAL correlator: sequence_scan on a small dense uint8 / 255 pair with its
+    x_corr_2d hook set to the reference's cross_correlate_2d at full overlap (one
+    output element: steps larger than the region), which is what the dense band
+    kernel evaluates.  cross_correlate_2d raises when a region clipped by the image
+    border is smaller than the template; the hook turns that into "no candidate"
+    (an all-NaN surface, which image_scan's comparisons skip), the only adjustment.'''
+    corr, _, svic, _ = ref
+    rng = np.random.default_rng(14)
+    h, w = 47, 112
+    base = rng.integers(0, 256, size=(h, w + 40)).astype(np.float64)
+    k = np.array([1, 2, 3, 2, 1]) / 9        # strong smoothing: neighbouring offsets score close to the best
+    base = np.apply_along_axis(lambda v: np.convolve(v, k, mode='same'), 1, base)
+    base = np.apply_along_axis(lambda v: np.convolve(v, k, mode='same'), 0, base)
+    base = np.clip(np.rint((base - 127.5) * 3 + 127.5), 0, 255).astype(np.uint8)
+    left = base[:, 20:20 + w].copy()
+    right = np.zeros_like(left)
+    right[:, :w // 3] = base[:, 20 - 1:20 - 1 + w // 3]                 # disparity +1: centre within CENTRE_TOL
+    right[:, w // 3:2 * w // 3] = base[:, 20 + w // 3 + 9:20 + 2 * w // 3 + 9]    # disparity -9
+    right[:, 2 * w // 3:] = base[:, 20 + 2 * w // 3:20 + w]             # disparity 0
+    noise = rng.integers(-6, 7, size=right.shape)
+    right = np.clip(right.astype(np.int32) + noise, 0, 255).astype(np.uint8)
+    cfg = [[{'window_width': 31, 'window_height': 31, 'scheme': [25, 1],
+             'scheme_shift_size': [1, 0], 'window_overlap': 0.96,
+             'correlation_threshold': 0.6}]]
+    big = 10 ** 6
+
+    def spatial_full_overlap(t, r):
+        if t.shape[0] > r.shape[0] or t.shape[1] > r.shape[1]:
+            return np.full((1, 1), np.nan)
+        with np.errstate(all='ignore'):
+            return corr.cross_correlate_2d(t, r, big, big)
+    orig = svic.x_corr_2d
+    svic.x_corr_2d = spatial_full_overlap
+    try:
+        out = run_scan(ref, left / 255.0, right / 255.0, cfg)
+    finally:
+        svic.x_corr_2d = orig
+    save('g14_dense_spatial_fold', left=left, right=right, config=np.array(json.dumps(cfg)), **out)
+
+
 def g12_greyscale_with_nan(ref):
     '''The reference's loader on its two RGBA images: decoded pixels in, grey
     levels with NaN for transparent pixels out.'''
@@ -464,6 +506,7 @@ GROUPS = {
     'g11': g11_find_peaks,
     'g12': g12_greyscale_with_nan,
     'g13': g13_spatial_nan_region,
+    'g14': g14_dense_spatial_fold,
 }
 
 

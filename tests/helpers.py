@@ -84,3 +84,33 @@ def oracle_select_local(tbase, rbase, desc, is_centre, skip, win_off, threshold,
                       ctypes.c_double(v.CENTRE_TOL), best_pair.ctypes.data_as(c_i64),
                       best_val.ctypes.data_as(c_d))
     return best_pair, best_val
+
+
+def check_band_fold_against_g14(band_scan_fold):
+    '''g14_dense_spatial_fold: the reference's sequence_scan (its own selection rule)
+    over its spatial correlator at full overlap, on a dense 31 x 31, 25-offset
+    config.  `band_scan_fold(left_u8, right_u8, win, max_disp, threshold)` must
+    return (disparity, correlation) per window origin; every window whose template
+    is full-size is compared: disparity exactly, correlation to 1e-12.'''
+    import json
+    g = golden('g14_dense_spatial_fold')
+    cfg = json.loads(str(g['config']))[0][0]
+    win, md, thr = cfg['window_width'], (cfg['scheme'][0] - 1) // 2, cfg['correlation_threshold']
+    left, right = g['left'], g['right']
+    h, w = left.shape
+    disp, val = band_scan_fold(left, right, win, md, thr)
+    assert disp.shape == (h - win + 1, w - win + 1)
+    rows = g['seq0_stage0_windows']      # id, row, column, cx, cy, dp_x, dp_y, ...
+    calls = g['seq0_calls']              # id, pos_x, pos_y, corr_max, n_regions
+    checked = moved = 0
+    for wrow, call in zip(rows, calls):
+        y, x = int(wrow[1]), int(wrow[2])
+        if y > h - win or x > w - win:
+            continue                     # template clipped by the image border: not a band-scan window
+        assert wrow[6] == 0
+        assert disp[y, x] == wrow[5], f'window ({y},{x}): disparity {disp[y, x]} != reference {wrow[5]}'
+        assert abs(val[y, x] - call[3]) <= 1e-12, f'window ({y},{x}): {val[y, x]} vs {call[3]}'
+        checked += 1
+        moved += wrow[5] != 0
+    assert checked == (h - win + 1) * (w - win + 1)
+    assert moved > checked // 4          # the fixture exercises non-centre selections

@@ -266,3 +266,11 @@ def test_resize_matches_ndimage(oracle, shape, factor, kind):
         close(got, ref, 1e-13)
     if shape[0] > 1:
         assert np.array_equal(oracle.downsample(image, factor), got, equal_nan=True)
+
+
+def test_g14_band_fold_matches_reference_rule(oracle):
+    '''The oracle's band scan in selection-rule mode against the reference's own
+    sequence_scan over its spatial correlator.'''
+    from helpers import check_band_fold_against_g14
+    check_band_fold_against_g14(
+        lambda left, right, win, md, thr: oracle.band_scan(left, right, win, win, md, mode='fold', threshold=thr))

@@ -527,6 +527,16 @@ def test_band_scan_matches_reference_band_row(mods):
         assert disp[0, 128] == int(np.nanargmax(g['surfaces'][i][0, :257])) - 128
 
 
+def test_g14_band_fold_matches_reference_rule(mods):
+    '''Selection-rule mode of the band kernel (the benchmark's mode) against the
+    reference's sequence_scan run over its spatial correlator.'''
+    from helpers import check_band_fold_against_g14
+    b = mods['b']
+    check_band_fold_against_g14(
+        lambda left, right, win, md, thr: b.band_scan(left / 255.0, right / 255.0, win, win, md,
+                                                      correlation_threshold=thr))
+
+
 def test_band_scan_rejects_unsupported(mods):
     b = mods['b']
     with pytest.raises(TypeError):
