@@ -5,19 +5,24 @@ candidate offsets (-128..+128), image_scan's selection rule fused in.
 
     python bench.py --gpus N --steps K --warmup W
 
-One process per GPU (torch.distributed over RCCL when N > 1).  Every rank scans
-its own pair per step (weak scaling: the job is a batch of N pairs, i.e. row
-bands of an N-times taller strip); only the per-window results (int16 disparity
-+ float32 correlation) are gathered to rank 0.  A step = summed-area tables +
-window statistics (K1) + the band kernel (K2) + the gather; the gather of step i
-is issued asynchronously and travels while step i + 1 computes (two result
-buffers take turns), every gather has completed before the clock stops.  Rank 0
-prints one JSON line.
+One process per GPU (torch.distributed over RCCL when N > 1).  The job is ONE
+pair per step, sharded over the ranks by bands of window rows (strong scaling):
+rank r holds the image rows of its band plus a halo of window_height - 1 rows,
+builds the summed-area tables and window statistics of that band only (K1), runs
+the band kernel on it (K2) and sends its per-window results (int16 disparity +
+float32 correlation, 6 bytes per window) to rank 0.  No other communication.  The
+gather of step i is issued asynchronously and travels while step i + 1 computes
+(two result buffers take turns); every gather has completed before the clock
+stops.  After the timed region rank 0 scans the whole pair alone once and checks
+that the gathered map equals it.  For N > 1 a second, untimed-by-the-contract
+measurement gives every rank a pair of its own (weak scaling) and is reported as
+`scaling_weak_value`.  Rank 0 prints one JSON line.
 
 metric: NCC window evaluations per second, an evaluation being one (window,
 offset) score = 2 * 31 * 31 algorithmic float32 flops of cross term.
-roofline: the band kernel alone, timed with HIP events on its stream, against
-the FP32 vector-ALU peak.  cpu_baseline: the C oracle (OpenMP) on a crop.
+roofline: the band kernel alone on rank 0, timed with HIP events on its stream,
+against the FP32 vector-ALU peak.  cpu_baseline (N = 1 only): the C oracle
+(OpenMP, every core granted) on a crop, plus one-thread numpy rows.
 '''
 import argparse
 import json
@@ -71,18 +76,76 @@ def measured_traffic():
         return None
 
 
-def count_evals(height, width, win, max_disp):
-    '''Number of (window, offset) pairs whose candidate box lies inside the image.'''
-    nwx, nwy = width - win + 1, height - win + 1
+def count_evals(height, width, win, max_disp, rows=None):
+    '''Number of (window, offset) pairs whose candidate box lies inside the image
+    (of `rows` window rows, default all).'''
+    nwx, nwy = width - win + 1, (height - win + 1 if rows is None else rows)
     x = np.arange(nwx)
     lo = np.maximum(x - max_disp, 0)
     hi = np.minimum(x + max_disp, nwx - 1)
     return int(nwy) * int((hi - lo + 1).sum())
 
 
+def numpy_rows(seed):
+    """One-thread numpy baselines of the same arithmetic on crops of the same pair:
+    (a) the reference's form, one Python-level NCC evaluation per (window, offset)
+    with numpy reductions over the 31 x 31 boxes (correlation.py:104-116 evaluated
+    at full overlap); (b) a vectorised numpy port (one product image per offset,
+    box sums through summed-area tables)."""
+    rows = []
+    left, right = synthetic_pair(WIN + 39, WIN + 63 + 2 * MAX_DISP, seed)
+    lf, rf = left.astype(np.float64), right.astype(np.float64)
+    n_eval = 0
+    t0 = time.perf_counter()
+    for y in range(left.shape[0] - WIN + 1):
+        for x in range(MAX_DISP, MAX_DISP + 64):
+            t = lf[y:y + WIN, x:x + WIN]
+            tc = t - t.mean()
+            ts = t.std()
+            for d in range(-MAX_DISP, MAX_DISP + 1, 8):           # every 8th offset: bounded sample
+                r = rf[y:y + WIN, x + d:x + d + WIN]
+                _ = np.sum(tc * (r - r.mean())) / t.size / (ts * r.std())
+                n_eval += 1
+    dt = time.perf_counter() - t0
+    rows.append({'value': n_eval / dt, 'unit': 'NCC window evals/s', 'cores': 1, 'kind': 'port',
+                 'sample': f'{n_eval} evaluations in {dt:.2f} s, one numpy NCC per (window, offset) '
+                           f'as the reference evaluates them'})
+    ch, cw = WIN + 255, WIN + 1023
+    left, right = synthetic_pair(ch, cw, seed)
+    lf, rf = left.astype(np.float64) - 128.0, right.astype(np.float64) - 128.0
+
+    def box(a):
+        sat = np.zeros((a.shape[0] + 1, a.shape[1] + 1))
+        np.cumsum(np.cumsum(a, axis=0), axis=1, out=sat[1:, 1:])
+        return sat[WIN:, WIN:] - sat[:-WIN, WIN:] - sat[WIN:, :-WIN] + sat[:-WIN, :-WIN]
+    t0 = time.perf_counter()
+    n = float(WIN * WIN)
+    sl, sr = box(lf), box(rf)
+    al, ar = n * box(lf * lf) - sl * sl, n * box(rf * rf) - sr * sr
+    nwx = cw - WIN + 1
+    best = np.full(sl.shape, -np.inf)
+    n_eval = 0
+    with np.errstate(all='ignore'):
+        for d in range(-MAX_DISP, MAX_DISP + 1):
+            lo, hi = max(0, -d), min(nwx, nwx - d)                # windows whose box at x + d is inside
+            if hi <= lo:
+                continue
+            prod = np.zeros_like(lf)
+            prod[:, lo:hi + WIN - 1] = lf[:, lo:hi + WIN - 1] * rf[:, lo + d:hi + d + WIN - 1]
+            score = (n * box(prod)[:, lo:hi] - sl[:, lo:hi] * sr[:, lo + d:hi + d]) / \
+                np.sqrt(al[:, lo:hi] * ar[:, lo + d:hi + d])
+            np.maximum(best[:, lo:hi], score, out=best[:, lo:hi])
+            n_eval += score.size
+    dt = time.perf_counter() - t0
+    rows.append({'value': n_eval / dt, 'unit': 'NCC window evals/s', 'cores': 1, 'kind': 'port',
+                 'sample': f'{ch}x{cw} crop, {n_eval} evaluations in {dt:.2f} s, vectorised numpy '
+                           f'(product image per offset + summed-area tables)'})
+    return rows
+
+
 def cpu_baseline(height, width, seed):
-    '''The C oracle's band scan (same semantics, float64, OpenMP over window rows)
-    on a crop of the same synthetic pair.'''
+    """The C oracle's band scan (same semantics, float64, OpenMP over window rows)
+    on a crop of the same synthetic pair; one-thread numpy rows beside it."""
     from oracle import ncc_oracle
     ncc_oracle.build()
     ch, cw = 31 + 1023, 31 + 1023       # 1024 x 1024 windows
@@ -92,9 +155,110 @@ def cpu_baseline(height, width, seed):
     ncc_oracle.band_scan(left, right, WIN, WIN, MAX_DISP, mode='fold', threshold=THRESHOLD)
     dt = time.perf_counter() - t0
     evals = count_evals(ch, cw, WIN, MAX_DISP)
-    return {'value': evals / dt, 'unit': 'NCC window evals/s', 'cores': cores, 'kind': 'port',
-            'sample': f'{ch}x{cw} crop of the same synthetic pair, {evals} evals in {dt:.2f} s '
-                      f'(oracle/ncc_oracle.c orc_band_scan, OpenMP)'}
+    out = {'value': evals / dt, 'unit': 'NCC window evals/s', 'cores': cores, 'kind': 'port',
+           'sample': f'{ch}x{cw} crop of the same synthetic pair, {evals} evals in {dt:.2f} s '
+                     f'(oracle/ncc_oracle.c orc_band_scan, OpenMP)',
+           'numpy_one_thread': numpy_rows(seed)}
+    try:
+        import numba  # noqa: F401
+        out['numba'] = 'importable but not timed: the reference\'s njit kernels are 1D only'
+    except ImportError:
+        out['numba'] = 'unavailable'
+    return out
+
+
+class Sharded:
+    """One rank's share of a scan: a band of window rows of one pair (its image rows
+    plus a halo of WIN - 1 rows) with the buffers its results travel in."""
+
+    def __init__(self, bs, torch, left, right, rows, world, rank, wire, wire_windows):
+        begin, end = rows
+        self.rows = rows
+        h = end - begin + WIN - 1
+        self.scanner = bs.BandScanner(h, left.shape[1], WIN, WIN, MAX_DISP)
+        self.scanner.upload(left[begin:begin + h], right[begin:begin + h])
+        self.nwin = self.scanner.disp.numel()
+        self.torch, self.world, self.rank, self.wire = torch, world, rank, wire
+        # Results travel as one byte buffer per rank: int16 disparities, then float32
+        # correlations (16-bit integers are not a collective dtype).  Every rank's
+        # buffer has the size of the largest share (shares differ by one window row at
+        # most): a gather wants equal sizes.
+        self.cap = cap = wire_windows
+        self.packed, self.disp16, self.val32 = [], [], []
+        for _ in range(2 if world > 1 else 0):          # two buffers take turns
+            buf = torch.zeros(6 * cap, dtype=torch.uint8, device='cuda')
+            self.packed.append(buf)
+            self.disp16.append(buf[:2 * cap].view(torch.int16)[:self.nwin].view(self.scanner.disp.shape))
+            self.val32.append(buf[2 * cap:].view(torch.float32)[:self.nwin].view(self.scanner.val.shape))
+        self.gathered = None
+        if world > 1 and rank == 0:
+            self.gathered = [[torch.empty(6 * cap, dtype=torch.uint8, device=wire) for _ in range(world)]
+                             for _ in range(2)]
+        self.in_flight = [None, None]
+        self.issued = 0
+
+    def step(self, dist, events=None):
+        sc = self.scanner
+        sc.prepare()                                        # K1: SATs + window statistics of the band
+        if events:
+            events[0].record()
+        sc.run(THRESHOLD, prepared=True)                    # K2: band kernel
+        if events:
+            events[1].record()
+        if self.world > 1:                                  # results -> rank 0 over RCCL
+            b = self.issued % 2
+            self.issued += 1
+            if self.in_flight[b] is not None:
+                self.in_flight[b].wait()                    # this buffer's previous gather has landed
+            self.disp16[b].copy_(sc.disp)
+            self.val32[b].copy_(sc.val)
+            self.in_flight[b] = dist.gather(self.packed[b].to(self.wire),
+                                            self.gathered[b] if self.rank == 0 else None, dst=0,
+                                            async_op=True)
+
+    def drain(self):
+        for b in range(2):
+            if self.in_flight[b] is not None:
+                self.in_flight[b].wait()
+                self.in_flight[b] = None
+
+    def last_gathered(self, counts):
+        """(disparity int16, correlation float32) of every rank's last step, on the
+        host, trimmed to that rank's `counts[r]` windows."""
+        b = (self.issued - 1) % 2
+        return [unpack_results(buf.cpu().numpy(), self.cap, n) for buf, n in zip(self.gathered[b], counts)]
+
+
+def unpack_results(raw, cap, n):
+    """A rank's wire buffer (uint8: `cap` int16 disparities, then `cap` float32
+    correlations) -> its first n windows."""
+    return raw[:2 * cap].view(np.int16)[:n].copy(), raw[2 * cap:].view(np.float32)[:n].copy()
+
+
+def timed(torch, dist, world, wire, job, steps, warmup, events=None):
+    """W untimed steps, then exactly K timed ones between barriers and device
+    synchronisations; the maximum over ranks."""
+    for _ in range(warmup):
+        job.step(dist)
+    job.drain()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        job.step(dist, (events[0][i], events[1][i]) if events else None)
+    job.drain()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=wire)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
 
 
 def main():
@@ -105,6 +269,7 @@ def main():
     ap.add_argument('--height', type=int, default=4096)
     ap.add_argument('--width', type=int, default=4096)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-weak', action='store_true', help='skip the secondary weak-scaling measurement')
     args = ap.parse_args()
 
     import torch
@@ -126,105 +291,78 @@ def main():
             dist.init_process_group('nccl', device_id=torch.device('cuda', device_index))
         else:
             dist.init_process_group(backend)
+    wire = 'cuda' if backend == 'nccl' else 'cpu'
 
     import band_scan as bs
+    import sharding
 
     H, W = args.height, args.width
-    left, right = synthetic_pair(H, W, seed=1000 + rank)
-    scanner = bs.BandScanner(H, W, WIN, WIN, MAX_DISP)
-    scanner.upload(left, right)
+    nwy, nwx = H - WIN + 1, W - WIN + 1
+    left, right = synthetic_pair(H, W, seed=1000)           # the same pair on every rank
+    bands = [sharding.shard_range(nwy, r, world) for r in range(world)]
+    counts = [(e - b) * nwx for b, e in bands]
+    job = Sharded(bs, torch, left, right, bands[rank], world, rank, wire, max(counts))
     evals = count_evals(H, W, WIN, MAX_DISP)
-
-    # results travel as one byte buffer per rank: int16 disparities then float32
-    # correlations (6 bytes per window; 16-bit integers are not a collective dtype)
-    nwin = scanner.disp.numel()
-    wire = 'cuda' if backend == 'nccl' else 'cpu'
-    packed, disp16, val32, gathered = [], [], [], []
-    for _ in range(2 if world > 1 else 0):          # two buffers take turns
-        buf = torch.empty(6 * nwin, dtype=torch.uint8, device='cuda')
-        packed.append(buf)
-        disp16.append(buf[:2 * nwin].view(torch.int16).view(scanner.disp.shape))
-        val32.append(buf[2 * nwin:].view(torch.float32).view(scanner.val.shape))
-        gathered.append([torch.empty(6 * nwin, dtype=torch.uint8, device=wire) for _ in range(world)]
-                        if rank == 0 else None)
-    in_flight = [None, None]
-    issued = [0]
+    my_evals = count_evals(H, W, WIN, MAX_DISP, rows=bands[rank][1] - bands[rank][0])
 
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-
-    def step(i=None):
-        scanner.prepare()                                   # K1: SATs + window statistics
-        if i is not None:
-            ev0[i].record()
-        scanner.run(THRESHOLD, prepared=True)               # K2: band kernel
-        if i is not None:
-            ev1[i].record()
-        if world > 1:                                       # results -> rank 0 over RCCL
-            b = issued[0] % 2
-            issued[0] += 1
-            if in_flight[b] is not None:
-                in_flight[b].wait()                         # this buffer's previous gather has landed
-            disp16[b].copy_(scanner.disp)
-            val32[b].copy_(scanner.val)
-            in_flight[b] = dist.gather(packed[b].to(wire), gathered[b], dst=0, async_op=True)
-
-    def drain():
-        for b in range(2):
-            if in_flight[b] is not None:
-                in_flight[b].wait()
-                in_flight[b] = None
-
-    for _ in range(args.warmup):
-        step()
-    drain()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-        torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    drain()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-        torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=wire)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
+    elapsed = timed(torch, dist, world, wire, job, args.steps, args.warmup, (ev0, ev1))
     kernel_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / args.steps
 
-    # sanity: the planted disparities are recovered on this rank's pair
-    disp = scanner.disp.cpu().numpy()
-    found = int((disp != 0).sum())
+    # the gathered map against one rank scanning the whole pair alone
+    check = None
+    found = None
+    if rank == 0:
+        if world > 1:
+            whole = bs.BandScanner(H, W, WIN, WIN, MAX_DISP)
+            whole.upload(left, right)
+            whole.run(THRESHOLD)
+            wd, wv = whole.disp.cpu().numpy(), whole.val.cpu().numpy().astype(np.float32)
+            parts = job.last_gathered(counts)
+            gd = np.concatenate([d for d, _ in parts]).reshape(nwy, nwx)
+            gv = np.concatenate([v for _, v in parts]).reshape(nwy, nwx)
+            check = bool(np.array_equal(gd, wd.astype(np.int16)) and np.array_equal(gv, wv))
+            found = int((gd != 0).sum())
+            del whole
+        else:
+            found = int((job.scanner.disp != 0).sum().item())
+
+    weak = None
+    if world > 1 and not args.no_weak:
+        # secondary: a pair of its own per rank (weak scaling), same step structure
+        del job
+        torch.cuda.empty_cache()
+        l2, r2 = synthetic_pair(H, W, seed=1000 + rank)
+        wjob = Sharded(bs, torch, l2, r2, (0, nwy), world, rank, wire, nwy * nwx)
+        wel = timed(torch, dist, world, wire, wjob, args.steps, args.warmup)
+        weak = world * evals * args.steps / wel
 
     if rank == 0:
-        flops_per_launch = evals * 2.0 * WIN * WIN
+        flops_per_launch = my_evals * 2.0 * WIN * WIN
         achieved = flops_per_launch / (kernel_ms * 1e-3) / 1e12
         line = {
             'metric': 'NCC window evals/sec (whole node)',
-            'value': world * evals * args.steps / elapsed,
+            'value': evals * args.steps / elapsed,
             'unit': 'NCC window evals/s',
             'n_gpus': world,
             'steps': args.steps,
             'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3,
             'higher_is_better': True,
-            'scaling': 'weak',
+            'scaling': 'strong',
             'vs_baseline': None,
             'dtype': 'f32',
             'data': 'synthetic',
             'config': {
-                'workload': f'dense band scan, synthetic {H}x{W} uint8 stereo pair per GPU, '
-                            f'{WIN}x{WIN} window at every pixel, {2 * MAX_DISP + 1} offsets '
-                            f'(-{MAX_DISP}..+{MAX_DISP}), selection rule threshold {THRESHOLD}',
+                'workload': f'dense band scan, ONE synthetic {H}x{W} uint8 stereo pair per step sharded over '
+                            f'{world} GPU(s) by bands of window rows, {WIN}x{WIN} window at every pixel, '
+                            f'{2 * MAX_DISP + 1} offsets (-{MAX_DISP}..+{MAX_DISP}), selection rule '
+                            f'threshold {THRESHOLD}',
                 'evals_per_pair': evals,
-                'pairs_per_step': world,
-                'windows_with_nonzero_disparity_rank0': found,
+                'pairs_per_step': 1,
+                'window_rows_per_rank': [e - b for b, e in bands],
+                'windows_with_nonzero_disparity': found,
             },
             'roofline': {
                 'bound': 'valu',
@@ -238,13 +376,20 @@ def main():
                 'traffic': None,
             },
         }
+        if check is not None:
+            line['config']['gathered_map_equals_single_gpu_scan'] = check
+        if weak is not None:
+            line['scaling_weak_value'] = weak
+            line['scaling_weak_note'] = f'{world} pairs per step, one per GPU, results gathered to rank 0'
         traffic = measured_traffic()
-        if traffic and (H, W) == (4096, 4096):
+        if traffic and (H, W) == (4096, 4096) and world == 1:
             line['roofline']['traffic'] = traffic['bytes_per_launch']
             line['roofline']['traffic_source'] = traffic['source']
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(H, W, seed=1000)
         print(json.dumps(line), flush=True)
+        if check is False:
+            raise SystemExit('the gathered disparity map differs from the single-GPU scan')
     if world > 1:
         dist.destroy_process_group()
 

@@ -78,3 +78,61 @@ def test_shard_range_covers_everything():
             assert spans[0][0] == 0 and spans[-1][1] == count
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert max(e - b for b, e in spans) - min(e - b for b, e in spans) <= 1
+
+
+def band_pair():
+    import bench
+    left, _ = bench.synthetic_pair(15 + 36, 15 + 80, seed=5)
+    return left, np.roll(left, 3, axis=1)
+
+
+def band_worker(rank, size, port, out_dir):
+    '''The benchmark's strong-scaling split on CPU: each rank scans its band of
+    window rows from a sub-image with a halo of win - 1 rows (the oracle stands in
+    for the band kernel), packs int16 disparities + float32 correlations into an
+    equal-sized byte buffer and rank 0 gathers them.'''
+    import torch
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=size)
+    try:
+        import bench
+        import sharding
+        from oracle import ncc_oracle
+        win, md = 15, 6
+        left, right = band_pair()
+        nwy, nwx = left.shape[0] - win + 1, left.shape[1] - win + 1
+        bands = [sharding.shard_range(nwy, r, size) for r in range(size)]
+        counts = [(e - b) * nwx for b, e in bands]
+        cap = max(counts)
+        b, e = bands[rank]
+        h = e - b + win - 1
+        disp, val = ncc_oracle.band_scan(left[b:b + h], right[b:b + h], win, win, md, mode='fold', threshold=0.5)
+        buf = np.zeros(6 * cap, dtype=np.uint8)
+        buf[:2 * cap].view(np.int16)[:counts[rank]] = disp.ravel()
+        buf[2 * cap:].view(np.float32)[:counts[rank]] = val.ravel()
+        gathered = [torch.empty(6 * cap, dtype=torch.uint8) for _ in range(size)] if rank == 0 else None
+        dist.gather(torch.from_numpy(buf), gathered, dst=0)
+        if rank == 0:
+            parts = [bench.unpack_results(g.numpy(), cap, n) for g, n in zip(gathered, counts)]
+            np.save(os.path.join(out_dir, 'disp.npy'), np.concatenate([d for d, _ in parts]).reshape(nwy, nwx))
+            np.save(os.path.join(out_dir, 'val.npy'), np.concatenate([v for _, v in parts]).reshape(nwy, nwx))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_band_rows_with_halo_gathered_equal_whole_scan(tmp_path, oracle):
+    import bench
+    size = 2
+    mp.spawn(band_worker, args=(size, free_port(), str(tmp_path)), nprocs=size, join=True)
+    left, right = band_pair()
+    disp, val = oracle.band_scan(left, right, 15, 15, 6, mode='fold', threshold=0.5)
+    assert np.array_equal(np.load(tmp_path / 'disp.npy'), disp.astype(np.int16))
+    assert np.array_equal(np.load(tmp_path / 'val.npy'), val.astype(np.float32))
+    assert (disp != 0).any()
+    # evaluation counts of the bands add up to the whole pair's
+    nwy = left.shape[0] - 15 + 1
+    total = bench.count_evals(left.shape[0], left.shape[1], 15, 6)
+    assert sum(bench.count_evals(left.shape[0], left.shape[1], 15, 6, rows=e - b)
+               for b, e in [(0, nwy // 2), (nwy // 2, nwy)]) == total
