@@ -117,7 +117,7 @@ int svamd_cross_correlate_1d(const double *v1, const double *v2, int64_t n, int 
 /* The same correlation for callers that cannot allocate or pass a workspace
  * (code under HIP graph capture, tight serving loops, harnesses that forbid
  * hipMalloc).  No counterpart in the reference.  The workspace is an array inside
- * the library's code object (about 18.6 MB per device, held until the process
+ * the library's code object (about 19.7 MB per device, held until the process
  * ends); the call allocates and frees nothing.  n is limited to
  * SVAMD_XCORR1D_STATIC_MAX_N samples (SVAMD_ERR_LIMIT beyond).  All calls on one
  * device share that array: calls that overlap in time on one device (different

@@ -20,15 +20,18 @@ int stats_launch(const void *src, int dtype, int h, int w, int64_t pitch, bool i
 // Sliding dot product of a float32 template over a float32 image:
 //   out[i][j] = sum_{m<th, n<tw} t[m][n] * img[i*sy + m][j*sx + n]
 // for i < oh, j < ow.  The image has eh valid rows of ew valid columns (row pitch
-// img_pitch, a multiple of 4 unless eh == 1); with sx == 1 anything beyond them
-// reads as 0, with sx > 1 the image must cover every index touched.  Products are
-// accumulated in float32 over short runs and the runs in float64.  `pack` and
-// `partial` are scratch of slide_pack_floats() floats / slide_partial_doubles()
-// doubles.
+// img_pitch, a multiple of 4 unless eh == 1); anything beyond them reads as 0
+// (rows: only with sx == 1; with sx > 1 the image must hold every row touched).
+// Products are accumulated in float32 over short runs and the runs in float64.
+// `pack`: slide_pack_floats() floats.  `partial`: with sx == 1
+// slide_partial_doubles() doubles; with sx > 1 `partial_cap` doubles, which
+// bounds how many ways the strided kernel may split the template columns
+// (slide_strided_partial_doubles() is the customary amount; 0 = no split).
 size_t slide_pack_floats(int th, int tw);
 size_t slide_partial_doubles(int tw, int64_t oh, int64_t ow);
+size_t slide_strided_partial_doubles(int64_t rh, int64_t rw);
 int slide_launch(const float *t, int th, int tw, const float *img, int64_t img_pitch, int eh, int ew,
                  int oh, int ow, int sx, int sy, double *out, float *pack, double *partial,
-                 hipStream_t stream);
+                 hipStream_t stream, size_t partial_cap = 0);
 
 }  // namespace svamd

@@ -76,6 +76,19 @@ sat_cols_kernel(int h, int w, TAcc *__restrict__ s1, TAcc *__restrict__ s2)
     TAcc *t = blockIdx.y == 0 ? s1 : s2;
     TAcc run = TAcc(0);
     int y = 1;
+    // the scan is a chain of memory round trips: the more rows are requested at a
+    // time, the fewer of them
+    for (; y + 32 <= h + 1; y += 32) {
+        TAcc v[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k)
+            v[k] = t[(int64_t)(y + k) * tp + x];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            run += v[k];
+            t[(int64_t)(y + k) * tp + x] = run;
+        }
+    }
     for (; y + 8 <= h + 1; y += 8) {
         TAcc v[8];
 #pragma unroll

@@ -146,10 +146,22 @@ __device__ __forceinline__ double centre_value(const Stats *st, int dtype)
     return dtype == SVAMD_U8 ? rint(st->mean) : st->mean;
 }
 
+// The mean of an array from the last entry of its summed-area table (exact for
+// integer tables).  Only `mean` and `count` are filled in.
+template <typename TSat>
+__global__ void mean_from_sat_kernel(const TSat *__restrict__ s1, int h, int w, Stats *__restrict__ out)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const double n = (double)h * (double)w;
+        out->mean = (double)s1[(int64_t)h * (w + 1) + w] / n;
+        out->std = 0.0;
+        out->count = n;
+        out->pad = 0.0;
+    }
+}
+
 // ---- operand preparation ----------------------------------------------------------
-// Mean-removed template in float32 (masked pixels -> 0) and, optionally, the
-// float64 summed-area table of the same values ((th+1) x (tw+1)), which gives the
-// sum of t' over any top-left crop.
+// Mean-removed template in float32 (masked pixels -> 0).
 __global__ void __launch_bounds__(256)
 prep_template_kernel(const void *__restrict__ t, int dtype, int th, int tw, int64_t pitch, int oh, int ow,
                      const Stats *__restrict__ st, float *__restrict__ tp)
@@ -161,30 +173,6 @@ prep_template_kernel(const void *__restrict__ t, int dtype, int th, int tw, int6
         int64_t y = i / ow, x = i - y * ow;
         double v = load_as_double(t, dtype, y * pitch + x);
         tp[i] = isnan(v) ? 0.0f : (float)(v - mean);
-    }
-}
-
-__global__ void __launch_bounds__(256)
-template_sat_kernel(const float *__restrict__ tp, int th, int tw, double *__restrict__ tsat)
-{
-    // small table: row prefixes by one thread per row, then column prefixes by
-    // one thread per column
-    const int tpw = tw + 1;
-    for (int y = threadIdx.x; y <= th; y += blockDim.x) {
-        double run = 0.0;
-        tsat[(int64_t)y * tpw] = 0.0;
-        for (int x = 0; x < tw; ++x) {
-            run += y == 0 ? 0.0 : (double)tp[(int64_t)(y - 1) * tw + x];
-            tsat[(int64_t)y * tpw + x + 1] = run;
-        }
-    }
-    __syncthreads();
-    for (int x = threadIdx.x; x <= tw; x += blockDim.x) {
-        double run = 0.0;
-        for (int y = 0; y <= th; ++y) {
-            run += tsat[(int64_t)y * tpw + x];
-            tsat[(int64_t)y * tpw + x] = run;
-        }
     }
 }
 
@@ -275,35 +263,226 @@ scale_1d_swapped_kernel(const double *__restrict__ raw, int64_t N, int64_t nt, c
     out[k] = raw[u] / (double)nt / s1->std;
 }
 
-// ---- the sliding dot product --------------------------------------------------------
-// Strided columns (sx > 1): one thread per output; a block covers 64 x 4 outputs.
-// Template values are wave-uniform and come in through the scalar data path.  Each
-// run of up to RUN products is accumulated in float32 and the runs are added in
-// float64, which keeps the rounding error of long sums near 1e-7 relative.
-constexpr int SLIDE_BX = 64, SLIDE_BY = 4, SLIDE_RUN = 128;
+typedef float f2v __attribute__((ext_vector_type(2)));
+typedef float f4v __attribute__((ext_vector_type(4)));
 
-__global__ void __launch_bounds__(SLIDE_BX *SLIDE_BY)
-slide_kernel(const float *__restrict__ t, int th, int tw, const float *__restrict__ img, int64_t pitch,
-             int oh, int ow, int sx, int sy, double *__restrict__ out)
+// ---- the sliding dot product --------------------------------------------------------
+// Strided columns (sx > 1).  Outputs sit sx image columns apart, so neighbouring
+// outputs share no aligned image data the way the unit-stride kernel exploits;
+// what they do share is image ROWS: image row r serves output row i as template
+// row r - i * sy.  A lane owns one output column and K consecutive output rows
+// (K = 8, 4, 2 or 1: the largest for which the rows of a group mostly overlap),
+// and every image value it reads feeds K FMAs against K wave-uniform template
+// values (scalar loads from a template padded with (K - 1) * sy zero rows above
+// and below, so that no row test is needed).
+//
+// The template's columns are cut into pieces of P = 4 * N4 columns (N4 = 1..3).
+// Per piece the image rows a group touches are walked in steps of 4; the (piece,
+// step) pairs of a tile of 64 output columns x K output rows form one list that
+// is dealt out in equal runs to the 4 wavefronts of a workgroup and to the
+// workgroups along the grid's z dimension (a 15 000-output scan would otherwise
+// occupy a fraction of the chip).  Staging is private to the wavefront (no
+// barriers): the part of row r that lane l needs,
+// img[r][(j0 + l) * sx + n0 ... + P), is loaded with neighbouring lanes on
+// neighbouring columns and stored as lane l's own segment; a lane then reads its
+// segment 16 bytes at a time.  Segment pitches of 4 * odd floats keep those reads
+// free of bank conflicts.  The loads of the next step are in flight while the
+// current one is computed, and so are the template values and the segment reads
+// of the next staged row (K * N4 <= 8 keeps two rows' template values in SGPRs).  Float32 sums are folded into float64
+// every SS_FLUSH products.  The four wavefronts add their sums through LDS; the
+// z slices go to partial planes that slide_reduce_kernel adds.
+constexpr int SS_WAVES = 4;       // wavefronts per workgroup
+constexpr int SS_ROWS = 4;        // image rows staged per step
+constexpr int SS_N4_MAX = 3;      // 16-byte groups per piece at most
+constexpr int SS_FLUSH = 1024;
+constexpr int SS_MAX_SLICES = 32;
+
+struct StridedGeom {
+    int th, tw, oh, ow, sx, sy;
+    int eh, ew;                   // valid image rows / columns
+    int64_t pitch;
+    int lp, padrows;              // padded template: row length (pieces * P), zero rows above (below: SS_ROWS more)
+    int npieces, iters_per_wave;
+};
+
+template <int K, int N4>
+__global__ void __launch_bounds__(SS_WAVES *WAVE)
+slide_strided_kernel(StridedGeom g, const float *__restrict__ tpad, const float *__restrict__ img,
+                     double *__restrict__ out)
 {
-    const int j = blockIdx.x * SLIDE_BX + threadIdx.x;
-    const int i = blockIdx.y * SLIDE_BY + threadIdx.y;
-    if (i >= oh || j >= ow)
-        return;
-    const float *base = img + (int64_t)i * sy * pitch + (int64_t)j * sx;
-    double acc = 0.0;
-    for (int m = 0; m < th; ++m) {
-        const float *trow = t + (int64_t)m * tw;
-        const float *irow = base + (int64_t)m * pitch;
-        for (int n0 = 0; n0 < tw; n0 += SLIDE_RUN) {
-            const int n1 = min(n0 + SLIDE_RUN, tw);
-            float part = 0.0f;
-            for (int n = n0; n < n1; ++n)
-                part = fmaf(trow[n], irow[n], part);
-            acc += (double)part;
+    constexpr int P = 4 * N4;                 // template columns per piece
+    constexpr int SEG = 4 * (N4 | 1);         // LDS floats per lane and staged row
+    constexpr int DQ = WAVE / P, DR = WAVE % P;
+    extern __shared__ __align__(16) float ss_lds[];
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
+    const int j0 = blockIdx.x * WAVE, i0 = blockIdx.y * K;
+    const int r_first = i0 * g.sy;
+    const int r_end = min((i0 + K - 1) * g.sy + g.th, g.eh);      // exclusive
+    const int nsteps = (r_end - r_first + SS_ROWS - 1) / SS_ROWS;
+    const int total = g.npieces * nsteps;
+    const int it_begin = min((int)(blockIdx.z * SS_WAVES + wave) * g.iters_per_wave, total);
+    const int it_end = min(it_begin + g.iters_per_wave, total);
+    float *wl = ss_lds + wave * (SS_ROWS * WAVE * SEG);
+    const int64_t krow = (int64_t)g.sy * g.lp;        // template floats between two output rows of a lane
+
+    float acc[K];
+    double dacc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        acc[k] = 0.f;
+        dacc[k] = 0.0;
+    }
+    // element e of a staged row = (lane segment e / P, column e % P); a lane takes
+    // e = lane, lane + 64, ...
+    const int l_first = lane / P, n_first = lane % P;
+    // image column (relative to the piece's first template column) and LDS slot of the
+    // lane's u-th element: the same for every row, piece and step
+    int col_of[P], slot_of[P];
+    {
+        int l = l_first, n = n_first;
+#pragma unroll
+        for (int u = 0; u < P; ++u) {
+            col_of[u] = (j0 + l) * g.sx + n;
+            slot_of[u] = l * SEG + n;
+            l += DQ;
+            n += DR;
+            if (n >= P) {
+                n -= P;
+                ++l;
+            }
         }
     }
-    out[(int64_t)i * ow + j] = acc;
+    float stage[SS_ROWS][P];
+    auto fetch = [&](int piece, int step) {
+        const int n0 = piece * P, r0 = r_first + step * SS_ROWS;
+        const int room = g.ew - n0;               // columns left of the image's right edge
+#pragma unroll
+        for (int rr = 0; rr < SS_ROWS; ++rr) {
+            const int r = r0 + rr;
+            const bool row_ok = r < r_end;
+            const float *src = img + (int64_t)r * g.pitch + n0;
+#pragma unroll
+            for (int u = 0; u < P; ++u)
+                stage[rr][u] = (row_ok && col_of[u] < room) ? src[col_of[u]] : 0.f;
+        }
+    };
+    auto store = [&]() {
+#pragma unroll
+        for (int rr = 0; rr < SS_ROWS; ++rr) {
+            float *dst = wl + rr * (WAVE * SEG);
+#pragma unroll
+            for (int u = 0; u < P; ++u)
+                dst[slot_of[u]] = stage[rr][u];
+        }
+    };
+
+    int pending = 0;
+    int piece = it_begin / nsteps, step = it_begin - piece * nsteps;
+    if (it_begin < it_end)
+        fetch(piece, step);
+    const float *lseg = wl + lane * SEG;
+    for (int it = it_begin; it < it_end; ++it) {
+        store();
+        int npiece = piece, nstep = step + 1;
+        if (nstep == nsteps) {
+            nstep = 0;
+            ++npiece;
+        }
+        if (it + 1 < it_end)
+            fetch(npiece, nstep);
+        // ---- K output rows against each staged row ----
+        // template row of output row i0 (k = 0) for the step's first image row; output
+        // row i0 + k uses the row k * sy above.  Rows staged beyond r_end are zeros and
+        // meet the SS_ROWS zero rows below the padded template.
+        const float *t0 = tpad + (int64_t)(step * SS_ROWS + g.padrows) * g.lp + piece * P;
+        // one unit = one staged row: its N4 segment reads and K * N4 template quads,
+        // requested one row ahead of their use (two register sets take turns)
+        f4v tv[2][K][N4], iv[2][N4];
+        auto load_row = [&](int rr, f4v (&t)[K][N4], f4v (&v)[N4]) {
+            const float *tp = t0 + (int64_t)rr * g.lp;
+#pragma unroll
+            for (int q = 0; q < N4; ++q)
+                v[q] = *reinterpret_cast<const f4v *>(lseg + rr * (WAVE * SEG) + 4 * q);
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+#pragma unroll
+                for (int q = 0; q < N4; ++q)
+                    t[k][q] = *reinterpret_cast<const f4v *>(tp - k * krow + 4 * q);
+        };
+        load_row(0, tv[0], iv[0]);
+#pragma unroll
+        for (int rr = 0; rr < SS_ROWS; ++rr) {
+            // this row's values have had the previous row's arithmetic to arrive; waiting
+            // for them here, before the next row's requests go out, keeps that wait from
+            // also covering requests made a moment ago (scalar loads return out of
+            // order, so any later wait would be for everything outstanding)
+            __builtin_amdgcn_s_waitcnt(0xc07f);       // lgkmcnt(0), the other counters left alone
+            __builtin_amdgcn_sched_barrier(0);
+            if (rr + 1 < SS_ROWS)
+                load_row(rr + 1, tv[(rr + 1) & 1], iv[(rr + 1) & 1]);
+#pragma unroll
+            for (int q = 0; q < N4; ++q) {
+                const f4v v = iv[rr & 1][q];
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const f4v t = tv[rr & 1][k][q];
+                    acc[k] = fmaf(t.x, v.x, acc[k]);
+                    acc[k] = fmaf(t.y, v.y, acc[k]);
+                    acc[k] = fmaf(t.z, v.z, acc[k]);
+                    acc[k] = fmaf(t.w, v.w, acc[k]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        pending += SS_ROWS * P;
+        if (pending >= SS_FLUSH) {
+            pending = 0;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                dacc[k] += (double)acc[k];
+                acc[k] = 0.f;
+            }
+        }
+        piece = npiece;
+        step = nstep;
+    }
+    // ---- the four wavefronts' sums, added in wavefront order ----
+    __syncthreads();
+    double *red = reinterpret_cast<double *>(ss_lds);
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+        red[(wave * K + k) * WAVE + lane] = dacc[k] + (double)acc[k];
+    __syncthreads();
+    if (wave != 0)
+        return;
+    const int j = j0 + lane;
+    if (j >= g.ow)
+        return;
+    double *dst = out + (int64_t)blockIdx.z * g.oh * g.ow;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        if (i0 + k >= g.oh)
+            break;
+        double sum = red[k * WAVE + lane];
+#pragma unroll
+        for (int w = 1; w < SS_WAVES; ++w)
+            sum += red[(w * K + k) * WAVE + lane];
+        dst[(int64_t)(i0 + k) * g.ow + j] = sum;
+    }
+}
+
+// Template with `padrows` zero rows above, `padrows` + SS_ROWS below, rows of lp floats.
+__global__ void __launch_bounds__(256)
+pad_template_kernel(const float *__restrict__ tp, int th, int tw, int lp, int padrows, float *__restrict__ tpad)
+{
+    const int64_t total = (int64_t)(th + 2 * padrows + SS_ROWS) * lp;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int n = (int)(i % lp);
+        const int m = (int)(i / lp) - padrows;
+        tpad[i] = (m >= 0 && m < th && n < tw) ? tp[(int64_t)m * tw + n] : 0.0f;
+    }
 }
 
 // Unit column stride (sx == 1): register-tiled, LDS-staged kernel.
@@ -343,9 +522,6 @@ struct SlideGeom {
     int waves, grows, rowlen;
     int nchunks, chunks_per_slice;   // template-column chunks, and how many of them a workgroup sums itself
 };
-
-typedef float f2v __attribute__((ext_vector_type(2)));
-typedef float f4v __attribute__((ext_vector_type(4)));
 
 // Packed template: for every row m, T0 = (t[m][0..tw-1], 0...) and T1 = (0, t[m][0..tw-1], 0...),
 // lp floats each.
@@ -526,7 +702,27 @@ static int slide_lp(int tw) { return (int)align_up((size_t)tw + 1, 8); }
 static int slide_chunks(int tw) { return (slide_lp(tw) + ST_CHUNK - 1) / ST_CHUNK; }
 constexpr int ST_MAX_SLICES = 16;   // partial-sum planes at most (workgroups sum the chunks of a slice themselves)
 
-size_t slide_pack_floats(int th, int tw) { return (size_t)th * 2 * slide_lp(tw); }
+// padded template row of the strided kernel: whole pieces (upper bound)
+static int strided_lp(int tw) { return (int)align_up((size_t)tw, 4) + 4 * SS_N4_MAX; }
+
+// Output rows per lane of the strided kernel: the largest K whose rows mostly
+// share their image rows ((K - 1) * sy <= th / 2, which also bounds the padded
+// template by twice the template).
+static int strided_rows_per_lane(int th, int sy)
+{
+    for (int k = 8; k > 1; k >>= 1)
+        if ((int64_t)(k - 1) * sy <= th / 2)
+            return k;
+    return 1;
+}
+
+// Operand buffer shared by both kernels: the unit-stride kernel's packed template
+// (two shifted copies of every row) or the strided kernel's padded template.
+size_t slide_pack_floats(int th, int tw)
+{
+    const size_t lp = (size_t)(slide_lp(tw) > strided_lp(tw) ? slide_lp(tw) : strided_lp(tw));
+    return ((size_t)th * 2 + SS_ROWS) * lp;
+}
 
 size_t slide_partial_doubles(int tw, int64_t oh, int64_t ow)
 {
@@ -535,17 +731,102 @@ size_t slide_partial_doubles(int tw, int64_t oh, int64_t ow)
     return planes > 1 ? (size_t)planes * (size_t)oh * (size_t)ow : 0;
 }
 
+// Partial planes of the strided kernel: a double per region pixel bounds the number
+// of z slices a strided scan may use (at least step_x * step_y of them fit).
+size_t slide_strided_partial_doubles(int64_t rh, int64_t rw) { return (size_t)(rh * rw + 256); }
+
+template <int K>
+static void strided_dispatch(int n4, dim3 grid, size_t lds, hipStream_t stream, const StridedGeom &g,
+                             const float *pack, const float *img, double *dst)
+{
+    // K * N4 <= 8 (strided_piece_groups keeps to it)
+    if constexpr (K <= 2) {
+        if (n4 == 3) {
+            hipLaunchKernelGGL((slide_strided_kernel<K, 3>), grid, dim3(SS_WAVES * WAVE), lds, stream, g, pack, img, dst);
+            return;
+        }
+    }
+    if constexpr (K <= 4) {
+        if (n4 == 2) {
+            hipLaunchKernelGGL((slide_strided_kernel<K, 2>), grid, dim3(SS_WAVES * WAVE), lds, stream, g, pack, img, dst);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((slide_strided_kernel<K, 1>), grid, dim3(SS_WAVES * WAVE), lds, stream, g, pack, img, dst);
+}
+
+// 16-byte groups per piece: among the widths whose template values for two rows fit
+// the scalar registers (K * N4 <= 8), the one that pads the template's columns
+// least, the wider on ties.
+static int strided_piece_groups(int K, int tw)
+{
+    const int most = K >= 8 ? 1 : K == 4 ? 2 : SS_N4_MAX;
+    int n4 = 1;
+    for (int c = 2; c <= most; ++c)
+        if ((tw + 4 * c - 1) / (4 * c) * c <= (tw + 4 * n4 - 1) / (4 * n4) * n4)
+            n4 = c;
+    return n4;
+}
+
+static int slide_strided_launch(const float *t, int th, int tw, const float *img, int64_t img_pitch, int eh,
+                                int ew, int oh, int ow, int sx, int sy, double *out, float *pack,
+                                double *partial, size_t partial_cap, hipStream_t stream)
+{
+    StridedGeom g;
+    g.th = th; g.tw = tw; g.oh = oh; g.ow = ow; g.sx = sx; g.sy = sy; g.eh = eh; g.ew = ew;
+    g.pitch = img_pitch;
+    const int K = strided_rows_per_lane(th, sy);
+    g.padrows = (K - 1) * sy;
+    const int64_t gx = ((int64_t)ow + WAVE - 1) / WAVE, gy = ((int64_t)oh + K - 1) / K;
+    SV_REQUIRE(gy <= 65535, SVAMD_ERR_LIMIT, "slide: too many output rows (%d)", oh);
+    const int n4 = strided_piece_groups(K, tw);
+    const int P = 4 * n4;
+    g.npieces = (tw + P - 1) / P;
+    g.lp = g.npieces * P;
+    // (piece, step) pairs of a full tile, dealt out to enough wavefronts for the chip;
+    // no more partial planes than the workspace holds
+    const int64_t steps = (((int64_t)(K - 1) * sy + th) + SS_ROWS - 1) / SS_ROWS;
+    const int64_t total = g.npieces * steps;
+    int64_t want = (4096 + gx * gy * SS_WAVES - 1) / (gx * gy * SS_WAVES);
+    const int64_t plane = (int64_t)oh * ow;
+    if (want > (int64_t)(partial_cap / (size_t)plane)) want = (int64_t)(partial_cap / (size_t)plane);
+    if (want > SS_MAX_SLICES) want = SS_MAX_SLICES;
+    if (want < 1) want = 1;
+    int64_t ipw = (total + want * SS_WAVES - 1) / (want * SS_WAVES);
+    if (ipw < 4) ipw = total < 4 ? total : 4;     // staging start-up is not worth fewer
+    g.iters_per_wave = (int)ipw;
+    const int nz = (int)((total + ipw * SS_WAVES - 1) / (ipw * SS_WAVES));
+    hipLaunchKernelGGL(pad_template_kernel, dim3(grid_for((int64_t)(th + 2 * g.padrows + SS_ROWS) * g.lp)), dim3(256), 0,
+                       stream, t, th, tw, g.lp, g.padrows, pack);
+    SV_LAUNCH_CHECK();
+    size_t lds = (size_t)SS_WAVES * SS_ROWS * WAVE * (4 * (n4 | 1)) * sizeof(float);
+    const size_t red = (size_t)SS_WAVES * K * WAVE * sizeof(double);
+    if (lds < red) lds = red;
+    dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)nz);
+    double *dst = nz > 1 ? partial : out;
+    switch (K) {
+    case 8: strided_dispatch<8>(n4, grid, lds, stream, g, pack, img, dst); break;
+    case 4: strided_dispatch<4>(n4, grid, lds, stream, g, pack, img, dst); break;
+    case 2: strided_dispatch<2>(n4, grid, lds, stream, g, pack, img, dst); break;
+    default: strided_dispatch<1>(n4, grid, lds, stream, g, pack, img, dst); break;
+    }
+    SV_LAUNCH_CHECK();
+    if (nz > 1) {
+        hipLaunchKernelGGL(slide_reduce_kernel, dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, stream,
+                           partial, nz, plane, out);
+        SV_LAUNCH_CHECK();
+    }
+    return SVAMD_OK;
+}
+
+// `partial_cap`: doubles available behind `partial` (only the strided kernel asks).
 int slide_launch(const float *t, int th, int tw, const float *img, int64_t img_pitch, int eh, int ew,
                  int oh, int ow, int sx, int sy, double *out, float *pack, double *partial,
-                 hipStream_t stream)
+                 hipStream_t stream, size_t partial_cap)
 {
-    if (sx != 1) {
-        dim3 grid((ow + SLIDE_BX - 1) / SLIDE_BX, (oh + SLIDE_BY - 1) / SLIDE_BY);
-        hipLaunchKernelGGL(slide_kernel, grid, dim3(SLIDE_BX, SLIDE_BY), 0, stream, t, th, tw, img,
-                           img_pitch, oh, ow, sx, sy, out);
-        SV_LAUNCH_CHECK();
-        return SVAMD_OK;
-    }
+    if (sx != 1)
+        return slide_strided_launch(t, th, tw, img, img_pitch, eh, ew, oh, ow, sx, sy, out, pack, partial,
+                                    partial_cap, stream);
     SlideGeom g;
     g.th = th; g.tw = tw; g.lp = slide_lp(tw);
     g.oh = oh; g.ow = ow; g.sy = sy; g.eh = eh; g.ew = ew; g.pitch = img_pitch;
@@ -705,9 +986,10 @@ extern "C" size_t svamd_cross_correlate_2d_workspace_bytes(int th, int tw, int r
     if (th <= 0 || tw <= 0 || rh <= 0 || rw <= 0)
         return 0;
     A1Layout L = a1_layout(th, tw, rh, rw);
-    return 2 * 256 + align_up(stats_scratch_doubles() * 8, 256) + align_up(L.n_tp * 4, 256) + align_up(L.n_tsat * 8, 256) +
+    return 2 * 256 + align_up(stats_scratch_doubles() * 8, 256) + align_up(L.n_tp * 4, 256) + 2 * align_up(L.n_tsat * 8, 256) +
            2 * align_up(L.n_sat * 8, 256) + align_up(L.n_ext * 4, 256) +
-           align_up(slide_pack_floats(th, tw) * 4, 256) + align_up(slide_partial_doubles(tw, rh, rw) * 8, 256);
+           align_up(slide_pack_floats(th, tw) * 4, 256) +
+           align_up((slide_partial_doubles(tw, rh, rw) + slide_strided_partial_doubles(rh, rw)) * 8, 256);
 }
 
 extern "C" int svamd_cross_correlate_2d(const double *tmpl, int th, int tw, const void *region,
@@ -734,27 +1016,38 @@ extern "C" int svamd_cross_correlate_2d(const double *tmpl, int th, int tw, cons
     double *sscr = ws.take<double>(stats_scratch_doubles());
     float *tp = ws.take<float>(L.n_tp);
     double *tsat = ws.take<double>(L.n_tsat);
+    double *tsat2 = ws.take<double>(L.n_tsat);
     void *s1 = ws.take<double>(L.n_sat);  // int64 or double: both 8 bytes
     void *s2 = ws.take<double>(L.n_sat);
     float *ext = ws.take<float>(L.n_ext);
     float *pack = ws.take<float>(slide_pack_floats(th, tw));
-    double *partial = ws.take<double>(slide_partial_doubles(tw, rh, rw));
+    const size_t partial_cap = slide_partial_doubles(tw, rh, rw) + slide_strided_partial_doubles(rh, rw);
+    double *partial = ws.take<double>(partial_cap);
 
     int rc;
     if ((rc = stats_launch(tmpl, SVAMD_F64, th, tw, tw, true, tst, sscr, st)) != SVAMD_OK) return rc;
-    if ((rc = stats_launch(region, region_dtype, rh, rw, rw, false, rst, sscr, st)) != SVAMD_OK) return rc;
     hipLaunchKernelGGL(prep_template_kernel, dim3(grid_for((int64_t)L.n_tp)), dim3(256), 0, st, tmpl,
                        SVAMD_F64, th, tw, (int64_t)tw, th, tw, tst, tp);
     SV_LAUNCH_CHECK();
-    hipLaunchKernelGGL(template_sat_kernel, dim3(1), dim3(256), 0, st, tp, th, tw, tsat);
-    SV_LAUNCH_CHECK();
+    // table of the centred template (sums over top-left crops); the table of its squares is not used
+    if ((rc = sat2d_launch<float, double>(tp, th, tw, tw, 0.0, tsat, tsat2, st)) != SVAMD_OK) return rc;
     rc = svamd_sat2d(region, region_dtype, rh, rw, rw, 0.0, s1, s2, stream);
     if (rc != SVAMD_OK) return rc;
+    // The region's mean only serves as the constant the pixels are centred by before
+    // they are rounded to float32 (the epilogue puts the window's own mean back): the
+    // table's last entry gives it without another pass over the region.
+    if (region_dtype == SVAMD_U8)
+        hipLaunchKernelGGL((mean_from_sat_kernel<int64_t>), dim3(1), dim3(64), 0, st,
+                           static_cast<const int64_t *>(s1), rh, rw, rst);
+    else
+        hipLaunchKernelGGL((mean_from_sat_kernel<double>), dim3(1), dim3(64), 0, st,
+                           static_cast<const double *>(s1), rh, rw, rst);
+    SV_LAUNCH_CHECK();
     hipLaunchKernelGGL(extend_kernel, dim3(grid_for((int64_t)L.n_ext)), dim3(256), 0, st, region,
                        region_dtype, rh, rw, (int64_t)rw, 0, 0, rst, L.eh, L.ew, L.epitch, ext);
     SV_LAUNCH_CHECK();
     if ((rc = slide_launch(tp, th, tw, ext, L.epitch, L.eh, L.ew, orows, ocols, step_x, step_y, out, pack,
-                           partial, st)) != SVAMD_OK)
+                           partial, st, partial_cap)) != SVAMD_OK)
         return rc;
     const int64_t total = (int64_t)orows * ocols;
     dim3 eg((unsigned)((total + 255) / 256));
@@ -890,7 +1183,7 @@ extern "C" int svamd_cross_correlate_1d(const double *v1, const double *v2, int6
 // comes from hipGetSymbolAddress, once per device.
 constexpr int64_t XCORR1D_STATIC_MAX_N = SVAMD_XCORR1D_STATIC_MAX_N;
 constexpr size_t XCORR1D_STATIC_BYTES = 2 * 256 + 2 * 512 * 8 /* statistics partials */ +
-                                        (size_t)XCORR1D_STATIC_MAX_N * (4 + 12 + 8 + 4) /* operands, slack */ +
+                                        (size_t)XCORR1D_STATIC_MAX_N * (4 + 12 + 24 + 4) /* operands, slack */ +
                                         (size_t)16 * 2 * XCORR1D_STATIC_MAX_N * 8 /* partial sums */ + 8 * 256;
 static __device__ __align__(256) unsigned char xcorr1d_scratch[XCORR1D_STATIC_BYTES];
 

@@ -110,6 +110,33 @@ def test_spatial_unit_column_stride_shapes(mods, oracle, tshape, rshape, sx, sy)
     assert_surface_close(out, oracle.cross_correlate_2d(template, fregion, sx, sy), SURFACE_TOL, 'float region')
 
 
+@pytest.mark.parametrize('tshape,rshape,sx,sy', [
+    ((135, 136), (433, 862), 5, 5),     # the step-5 driver case: 8 output rows per lane, columns split 9 ways
+    ((9, 7), (60, 300), 2, 9),          # rows of a group share nothing: one output row per lane
+    ((40, 210), (90, 700), 3, 4),       # wide template: several pieces per wavefront
+    ((17, 5), (200, 130), 7, 1),        # narrow template, unit row step
+    ((33, 33), (33, 33), 2, 2),         # template as large as the region: every placement but one overhangs
+    ((12, 50), (64, 1500), 11, 3)])
+def test_spatial_strided_columns_vs_oracle(mods, oracle, tshape, rshape, sx, sy):
+    '''Column steps above 1 run the strided kernel (a lane owns one output column
+    and up to 8 output rows; template columns split over wavefronts and grid
+    slices): every output, incl. the overhanging bottom/right placements and a
+    NaN-masked template, against the oracle.'''
+    rng = np.random.default_rng(tshape[0] * 7 + sx)
+    template = rng.random(tshape) * 255
+    template[rng.random(tshape) < 0.2] = np.nan
+    region = rng.integers(0, 256, size=rshape, dtype=np.uint8)
+    got = quiet(mods['c'].cross_correlate_2d, template, region, sx, sy)
+    want = oracle.cross_correlate_2d(template, region, sx, sy)
+    assert got.shape == (-(-rshape[0] // sy), -(-rshape[1] // sx))
+    assert_surface_close(got, want, SURFACE_TOL, f'strided {tshape} over {rshape} step ({sx},{sy})')
+    # float region, no mask
+    regf = rng.random(rshape)
+    got = quiet(mods['c'].cross_correlate_2d, np.nan_to_num(template), regf, sx, sy)
+    want = oracle.cross_correlate_2d(np.nan_to_num(template), regf, sx, sy)
+    assert_surface_close(got, want, SURFACE_TOL, f'strided float {tshape} over {rshape}')
+
+
 def test_spatial_template_exceeds_region(mods):
     with pytest.raises(Exception, match='Dimensions of template must not exceed those of region.'):
         mods['c'].cross_correlate_2d(np.zeros((5, 5)), np.zeros((4, 9), np.uint8))
