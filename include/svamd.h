@@ -85,7 +85,12 @@ int svamd_cross_correlate_2d(const double *tmpl, int th, int tw,
 /* ---- a2: cross_correlate_2d_spectral(template, region) ------------------------
  * correlation_spectral.py:32-55.  out: rh x rw float64 (the circular,
  * globally normalised surface).  min_std / min_mean_diff are the module
- * constants MIN_ST_DEV / MIN_MEAN_DIFF (correlation_spectral.py:6,10). */
+ * constants MIN_ST_DEV / MIN_MEAN_DIFF (correlation_spectral.py:6,10).
+ * Any shapes.  Evaluated directly (a sliding dot product over the wrapped region)
+ * or, when that would take more than 2e10 products and the template (cropped to
+ * the region) covers at least a quarter of the region, through FFTs of both
+ * operands zero-padded to powers of two (up to 4096 per side), which keeps the
+ * circular semantics of the original shape exactly. */
 size_t svamd_cross_correlate_2d_spectral_workspace_bytes(int th, int tw, int rh, int rw);
 int svamd_cross_correlate_2d_spectral(const void *tmpl, int tmpl_dtype, int th, int tw,
                                       const void *region, int region_dtype, int rh, int rw,
@@ -94,13 +99,13 @@ int svamd_cross_correlate_2d_spectral(const void *tmpl, int tmpl_dtype, int th, 
 
 /* ---- a2, batched, power-of-two shapes: the FFT route of correlation_spectral.py:51-54 --
  * `batch` independent pairs: templates [batch][th][tw] and regions [batch][H][W],
- * float32, H and W powers of two in 4..1024 (svamd_fft_supported).  Same
+ * float32, H and W powers of two in 4..4096 (svamd_fft_supported).  Same
  * semantics as svamd_cross_correlate_2d_spectral (statistics over the full
  * arrays, template zero-padded or cropped top-left to H x W, low-deviation
  * branch); evaluated by a radix-4 FFT in LDS: packed row transforms, column
  * transforms fused with the conjugate multiply and the inverse column transform,
- * inverse row transforms.  out: [batch][H][W] of out_dtype (SVAMD_F32 or
- * SVAMD_F64). */
+ * inverse row transforms (1024 x 1024 has kernels of its own: one wavefront
+ * per transform).  out: [batch][H][W] of out_dtype (SVAMD_F32 or SVAMD_F64). */
 int svamd_fft_supported(int H, int W);
 size_t svamd_xcorr2d_fft_workspace_bytes(int batch, int H, int W);
 int svamd_xcorr2d_fft(const float *tmpl, int th, int tw, const float *region, int H, int W,

@@ -610,12 +610,9 @@ static int band_launch(const BandGeom &g, size_t lds, dim3 grid, hipStream_t st,
                        const uint8_t *right, const int32_t *wl, const double *il, const int32_t *wr,
                        const double *ir, int32_t *out_disp, double *out_val, double *scores)
 {
-    static bool raised = false;
-    if (!raised) {
-        SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&band_scan_kernel<WIN_W>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, BAND_LDS_LIMIT));
-        raised = true;
-    }
+    // per function and per device: set before every launch (a process may drive several devices)
+    SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&band_scan_kernel<WIN_W>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, BAND_LDS_LIMIT));
     hipLaunchKernelGGL((band_scan_kernel<WIN_W>), grid, dim3(BAND_THREADS), lds, st, g, left, right, wl, il,
                        wr, ir, out_disp, out_val, scores);
     SV_LAUNCH_CHECK();

@@ -1,5 +1,5 @@
 // K3-large: batched circular 2D cross-correlation through FFTs held in LDS, for
-// power-of-two region shapes (rows and columns 16..1024).  Per pair:
+// power-of-two region shapes (rows and columns 4..4096).  Per pair:
 //
 //   pass 1 (rows)     z = (t - mean t) + i (r - mean r) per image row, one complex
 //                     FFT of length W in LDS, split into the two half spectra
@@ -24,8 +24,8 @@
 
 namespace svamd {
 
-constexpr int FFT_MAX_N = 1024;
-constexpr int FFT_COLS = 8;          // spectrum columns per tile in pass 2
+constexpr int FFT_MAX_N = 4096;
+constexpr int FFT_COLS = 8;          // spectrum columns per tile in pass 2 (fewer for more than 1024 rows)
 constexpr int FFT_THREADS = 256;
 
 struct FftStats {                    // per pair
@@ -193,18 +193,22 @@ fft_stats_kernel(const float *__restrict__ t, int64_t t_elems, const float *__re
 
 // ---- pass 1: packed row transform ---------------------------------------------------
 // One workgroup per (row, pair).  spec_t / spec_r: [pair][H][hp] complex, hp = W/2 + 16.
+// raw != 0: the arrays are transformed as they are (no mean removed).
 __global__ void __launch_bounds__(FFT_THREADS)
 fft_rows_forward_kernel(const float *__restrict__ t, int th, int tw_, const float *__restrict__ r, int H,
                         int W, int log2w, const FftStats *__restrict__ stats,
                         const float2 *__restrict__ twiddle, float2 *__restrict__ spec_t,
-                        float2 *__restrict__ spec_r, int hp)
+                        float2 *__restrict__ spec_r, int hp, int raw)
 {
-    __shared__ float2 buf[FFT_MAX_N];
-    __shared__ float2 twl[FFT_MAX_N];
+    extern __shared__ __align__(16) float2 rows_lds[];
+    float2 *buf = rows_lds, *twl = rows_lds + W;
     const int y = blockIdx.x, pair = blockIdx.y;
-    const FftStats st = stats[pair];
-    const float tmean = (float)(st.t_sum / ((double)th * tw_));
-    const float rmean = (float)(st.r_sum / ((double)H * W));
+    float tmean = 0.f, rmean = 0.f;
+    if (!raw) {
+        const FftStats st = stats[pair];
+        tmean = (float)(st.t_sum / ((double)th * tw_));
+        rmean = (float)(st.r_sum / ((double)H * W));
+    }
     const float *trow = t + ((int64_t)pair * th + y) * tw_;
     const float *rrow = r + ((int64_t)pair * H + y) * W;
     const int mh = min(th, H), mw = min(tw_, W);   // template zero-padded or cropped to the region
@@ -228,78 +232,84 @@ fft_rows_forward_kernel(const float *__restrict__ t, int th, int tw_, const floa
 }
 
 // ---- pass 2: column transforms, conjugate multiply, inverse column transform --------
-// One workgroup per (tile of FFT_COLS spectrum columns, pair).  The T and R tiles
-// are interleaved in LDS as [H][2 * FFT_COLS] so that one call transforms all 16
+// One workgroup per (tile of `cols` spectrum columns, pair).  The T and R tiles are
+// interleaved in LDS as [H][2 * cols] so that one call transforms all 2 * cols
 // sequences; P = conj(T) R overwrites the T half, whose inverse transform is then
-// stored over spec_t.
+// stored over spec_t.  cols = 8 up to 1024 rows, 4 for 2048, 2 for 4096 (the tile
+// and the twiddle table then fill the 160 KB of LDS).
 constexpr int FFT_COL_THREADS = 1024;
 
 __global__ void __launch_bounds__(FFT_COL_THREADS)
 fft_cols_fused_kernel(float2 *__restrict__ spec_t, const float2 *__restrict__ spec_r, int H, int log2h,
-                      int ncols, int hp, const float2 *__restrict__ twiddle)
+                      int ncols, int hp, int cols, const float2 *__restrict__ twiddle)
 {
     extern __shared__ __align__(16) float2 lds[];
-    constexpr int S = 2 * FFT_COLS;
+    const int S = 2 * cols;
     float2 *tile = lds;                     // [H][S]
     float2 *twl = lds + H * S;              // [H]
-    const int c0 = blockIdx.x * FFT_COLS, pair = blockIdx.y;
+    const int c0 = blockIdx.x * cols, pair = blockIdx.y;
     float2 *gt = spec_t + (int64_t)pair * H * hp;
     const float2 *gr = spec_r + (int64_t)pair * H * hp;
-    for (int i = threadIdx.x; i < H * FFT_COLS; i += blockDim.x) {
-        const int y = i / FFT_COLS, c = i % FFT_COLS;
+    for (int i = threadIdx.x; i < H * cols; i += blockDim.x) {
+        const int y = i / cols, c = i % cols;
         const bool in = c0 + c < ncols;
         tile[y * S + c] = in ? gt[(int64_t)y * hp + c0 + c] : make_float2(0.f, 0.f);
-        tile[y * S + FFT_COLS + c] = in ? gr[(int64_t)y * hp + c0 + c] : make_float2(0.f, 0.f);
+        tile[y * S + cols + c] = in ? gr[(int64_t)y * hp + c0 + c] : make_float2(0.f, 0.f);
     }
     for (int i = threadIdx.x; i < H; i += blockDim.x)
         twl[i] = twiddle[i];
     __syncthreads();
     fft_forward(tile, H, log2h, S, S, twl);
-    for (int i = threadIdx.x; i < H * FFT_COLS; i += blockDim.x) {
-        const int y = i / FFT_COLS, c = i % FFT_COLS;
-        const float2 tv = tile[y * S + c], rv = tile[y * S + FFT_COLS + c];
+    for (int i = threadIdx.x; i < H * cols; i += blockDim.x) {
+        const int y = i / cols, c = i % cols;
+        const float2 tv = tile[y * S + c], rv = tile[y * S + cols + c];
         tile[y * S + c] = cmul_conj(rv, tv);            // conj(T) * R
     }
     __syncthreads();
-    fft_inverse(tile, H, log2h, FFT_COLS, S, twl);
-    for (int i = threadIdx.x; i < H * FFT_COLS; i += blockDim.x) {
-        const int y = i / FFT_COLS, c = i % FFT_COLS;
+    fft_inverse(tile, H, log2h, cols, S, twl);
+    for (int i = threadIdx.x; i < H * cols; i += blockDim.x) {
+        const int y = i / cols, c = i % cols;
         if (c0 + c < ncols)
             gt[(int64_t)y * hp + c0 + c] = tile[y * S + c];
     }
 }
 
 // ---- pass 3: inverse row transform of two rows at a time, scaling ---------------------
+// raw != 0: the plain circular correlation sum (scaled by 1 / (H W) only).
 template <typename TOut>
 __global__ void __launch_bounds__(FFT_THREADS)
 fft_rows_inverse_kernel(const float2 *__restrict__ spec, int th, int tw_, int H, int W, int log2w, int hp,
                         const FftStats *__restrict__ stats, double min_std, double min_mean_diff,
-                        const float2 *__restrict__ twiddle, TOut *__restrict__ out)
+                        const float2 *__restrict__ twiddle, TOut *__restrict__ out, int raw)
 {
-    __shared__ float2 buf[FFT_MAX_N];
-    __shared__ float2 twl[FFT_MAX_N];
+    extern __shared__ __align__(16) float2 rows_lds[];
+    float2 *buf = rows_lds, *twl = rows_lds + W;
     const int y0 = 2 * blockIdx.x, pair = blockIdx.y;
-    const FftStats st = stats[pair];
-    const double tn = (double)th * tw_, rn = (double)H * W;
-    const double tmean = st.t_sum / tn, rmean = st.r_sum / rn;
-    const double tvar = st.t_sq / tn - tmean * tmean, rvar = st.r_sq / rn - rmean * rmean;
-    const double tstd = sqrt(fmax(tvar, 0.0));
-    // a one-pass variance cannot resolve a relative spread below ~1e-14: constant region
-    const double rstd = rvar > 1e-14 * (st.r_sq / rn) ? sqrt(rvar) : 0.0;
     TOut *o0 = out + ((int64_t)pair * H + y0) * W;
     TOut *o1 = o0 + W;
     const bool second = y0 + 1 < H;
-    if (tstd < min_std || rstd == 0.0) {
-        // homogeneous template: constant surface; constant region: the reference
-        // divides 0 by 0 and every element is NaN
-        const TOut fill = tstd < min_std ? (fabs(tmean - rmean) < min_mean_diff ? TOut(1) : TOut(0))
-                                         : TOut(NAN);
-        for (int x = threadIdx.x; x < W; x += blockDim.x) {
-            o0[x] = fill;
-            if (second)
-                o1[x] = fill;
+    double scale = 1.0 / ((double)H * (double)W);
+    if (!raw) {
+        const FftStats st = stats[pair];
+        const double tn = (double)th * tw_, rn = (double)H * W;
+        const double tmean = st.t_sum / tn, rmean = st.r_sum / rn;
+        const double tvar = st.t_sq / tn - tmean * tmean, rvar = st.r_sq / rn - rmean * rmean;
+        const double tstd = sqrt(fmax(tvar, 0.0));
+        // a one-pass variance cannot resolve a relative spread below ~1e-14: constant region
+        const double rstd = rvar > 1e-14 * (st.r_sq / rn) ? sqrt(rvar) : 0.0;
+        if (tstd < min_std || rstd == 0.0) {
+            // homogeneous template: constant surface; constant region: the reference
+            // divides 0 by 0 and every element is NaN
+            const TOut fill = tstd < min_std ? (fabs(tmean - rmean) < min_mean_diff ? TOut(1) : TOut(0))
+                                             : TOut(NAN);
+            for (int x = threadIdx.x; x < W; x += blockDim.x) {
+                o0[x] = fill;
+                if (second)
+                    o1[x] = fill;
+            }
+            return;
         }
-        return;
+        scale = scale / (tstd * tn) / rstd;
     }
     const float2 *p0 = spec + ((int64_t)pair * H + y0) * hp;
     const float2 *p1 = second ? p0 + hp : p0;
@@ -319,7 +329,6 @@ fft_rows_inverse_kernel(const float2 *__restrict__ spec, int th, int tw_, int H,
     }
     __syncthreads();
     fft_inverse(buf, W, log2w, 1, 1, twl);
-    const double scale = 1.0 / ((double)H * (double)W) / (tstd * tn) / rstd;
     for (int x = threadIdx.x; x < W; x += blockDim.x) {
         o0[x] = (TOut)((double)buf[x].x * scale);
         if (second)
@@ -342,7 +351,74 @@ fft_rows_inverse_kernel(const float2 *__restrict__ spec, int th, int tw_, int H,
 constexpr int F1K = 1024;
 constexpr int F1K_LDS = F1K + 4 * (F1K / 64);     // padded elements per sequence
 
-__device__ __forceinline__ int f1k_idx(int p) { return p + 4 * (p >> 6); }
+// Position p of a sequence in LDS.  Besides the padding, every other block of 64
+// positions has the two 16-byte halves of each run of four positions exchanged:
+// the 32-byte reads and writes of positions 4 (lane + 64 u) + e, e = 0..3, start 8
+// banks apart from lane to lane, so lanes 16 apart would meet on the same banks
+// (the 16-lane groups of a 16-byte access mix lanes of both kinds: {0-3, 12-15,
+// 20-27}, ...); with the halves exchanged they land on the other half of each 32
+// bytes.  The other two access patterns (positions lane + 64 m and
+// 64 (lane / 4) + lane % 4 + 4 m) stay free of conflicts under the exchange.
+__device__ __forceinline__ int f1k_idx(int p)
+{
+    p ^= (p >> 5) & 2;
+    return p + 4 * (p >> 6);
+}
+
+// The per-stage twiddle factors of the wavefront transforms, each stage's in the order
+// its lanes read them (neighbouring lanes read neighbouring entries, or a few lanes'
+// worth is broadcast): reads of the plain table exp(-2 pi i k / 1024) at strides 2, 4,
+// 8, 12, ... elements would pile onto a few banks.
+//   [0, 768)     length 1024:  w^j, w^2j, w^3j for j = 0..255
+//   [768, 960)   length 256:   w^4l, w^8l, w^12l for l = 0..63
+//   [960, 1008)  length 64:    w^16j, w^32j, w^48j for j = 0..15
+//   [1008, 1020) length 16:    w^64s, w^128s, w^192s for s = 0..3
+constexpr int F1K_TW = 1024;     // entries (1020 used)
+__device__ __forceinline__ void f1k_load_twiddles(float2 *tw, const float2 *__restrict__ table, int tid, int nthreads)
+{
+    for (int i = tid; i < 1020; i += nthreads) {
+        int k;
+        if (i < 768)
+            k = (i / 256 + 1) * (i % 256);
+        else if (i < 960)
+            k = ((i - 768) / 64 + 1) * 4 * ((i - 768) % 64);
+        else if (i < 1008)
+            k = ((i - 960) / 16 + 1) * 16 * ((i - 960) % 16);
+        else
+            k = ((i - 1008) / 4 + 1) * 64 * ((i - 1008) % 4);
+        tw[i] = table[k];
+    }
+}
+
+// v[4 u + e] <-> position 4 (lane + 64 u) + e, as two explicit 16-byte accesses per u
+// (the exchanged halves of f1k_idx spelled out, so that they stay 16-byte accesses).
+__device__ __forceinline__ void f1k_read_quads(float2 (&v)[16], const float2 *x, int lane)
+{
+    const int f = (lane >> 3) & 2;          // bit 6 of the position -> which half comes first
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int p = 4 * (lane + 64 * u);
+        const float2 *base = x + p + 4 * (p >> 6);
+        const float4 lo = *reinterpret_cast<const float4 *>(base + f);
+        const float4 hi = *reinterpret_cast<const float4 *>(base + (2 ^ f));
+        v[4 * u] = make_float2(lo.x, lo.y);
+        v[4 * u + 1] = make_float2(lo.z, lo.w);
+        v[4 * u + 2] = make_float2(hi.x, hi.y);
+        v[4 * u + 3] = make_float2(hi.z, hi.w);
+    }
+}
+__device__ __forceinline__ void f1k_write_quads(const float2 (&v)[16], float2 *x, int lane)
+{
+    const int f = (lane >> 3) & 2;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int p = 4 * (lane + 64 * u);
+        float2 *base = x + p + 4 * (p >> 6);
+        *reinterpret_cast<float4 *>(base + f) = make_float4(v[4 * u].x, v[4 * u].y, v[4 * u + 1].x, v[4 * u + 1].y);
+        *reinterpret_cast<float4 *>(base + (2 ^ f)) =
+            make_float4(v[4 * u + 2].x, v[4 * u + 2].y, v[4 * u + 3].x, v[4 * u + 3].y);
+    }
+}
 
 // Layout of the half spectra between the 1024 x 1024 passes: [pair][group of 4
 // columns][row][4 columns].  The column pass works on one group at a time, which is
@@ -393,16 +469,17 @@ __device__ __forceinline__ void dit4_plain(float2 &a, float2 &b, float2 &c, floa
 
 // Forward transform.  In: v[m] = position lane + 64 m (natural order).  Out:
 // v[4 u + e] = position 4 (lane + 64 u) + e of the digit-reversed spectrum.
-// x: this wavefront's LDS region (F1K_LDS elements); tw: exp(-2 pi i k / 1024).
+// x: this wavefront's LDS region (F1K_LDS elements); tw: the staged twiddle tables
+// (f1k_load_twiddles).
 __device__ __forceinline__ void f1k_forward(float2 (&v)[16], float2 *x, const float2 *__restrict__ tw, int lane)
 {
 #pragma unroll
     for (int m0 = 0; m0 < 4; ++m0) {               // length 1024
         const int j = lane + 64 * m0;
-        dif4(v[m0], v[m0 + 4], v[m0 + 8], v[m0 + 12], tw[j], tw[2 * j], tw[3 * j]);
+        dif4(v[m0], v[m0 + 4], v[m0 + 8], v[m0 + 12], tw[j], tw[256 + j], tw[512 + j]);
     }
     {
-        const float2 w1 = tw[4 * lane], w2 = tw[8 * lane], w3 = tw[12 * lane];   // length 256
+        const float2 w1 = tw[768 + lane], w2 = tw[832 + lane], w3 = tw[896 + lane];   // length 256
 #pragma unroll
         for (int g = 0; g < 4; ++g)
             dif4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3], w1, w2, w3);
@@ -419,10 +496,10 @@ __device__ __forceinline__ void f1k_forward(float2 (&v)[16], float2 *x, const fl
 #pragma unroll
     for (int m0 = 0; m0 < 4; ++m0) {               // length 64
         const int j = s + 4 * m0;
-        dif4(v[m0], v[m0 + 4], v[m0 + 8], v[m0 + 12], tw[16 * j], tw[32 * j], tw[48 * j]);
+        dif4(v[m0], v[m0 + 4], v[m0 + 8], v[m0 + 12], tw[960 + j], tw[976 + j], tw[992 + j]);
     }
     {
-        const float2 w1 = tw[64 * s], w2 = tw[128 * s], w3 = tw[192 * s];        // length 16
+        const float2 w1 = tw[1008 + s], w2 = tw[1012 + s], w3 = tw[1016 + s];     // length 16
 #pragma unroll
         for (int h = 0; h < 4; ++h)
             dif4(v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3], w1, w2, w3);
@@ -431,11 +508,7 @@ __device__ __forceinline__ void f1k_forward(float2 (&v)[16], float2 *x, const fl
     for (int m = 0; m < 16; ++m)
         x[f1k_idx(64 * blk + s + 4 * m)] = v[m];
     __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            v[4 * u + e] = x[f1k_idx(4 * (lane + 64 * u) + e)];
+    f1k_read_quads(v, x, lane);
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int u = 0; u < 4; ++u)                    // length 4
@@ -449,11 +522,7 @@ __device__ __forceinline__ void f1k_inverse(float2 (&v)[16], float2 *x, const fl
 #pragma unroll
     for (int u = 0; u < 4; ++u)                    // length 4
         dit4_plain(v[4 * u], v[4 * u + 1], v[4 * u + 2], v[4 * u + 3]);
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            x[f1k_idx(4 * (lane + 64 * u) + e)] = v[4 * u + e];
+    f1k_write_quads(v, x, lane);
     __builtin_amdgcn_wave_barrier();
     const int blk = lane >> 2, s = lane & 3;
 #pragma unroll
@@ -461,7 +530,7 @@ __device__ __forceinline__ void f1k_inverse(float2 (&v)[16], float2 *x, const fl
         v[m] = x[f1k_idx(64 * blk + s + 4 * m)];
     __builtin_amdgcn_wave_barrier();
     {
-        const float2 w1 = tw[64 * s], w2 = tw[128 * s], w3 = tw[192 * s];        // length 16
+        const float2 w1 = tw[1008 + s], w2 = tw[1012 + s], w3 = tw[1016 + s];     // length 16
 #pragma unroll
         for (int h = 0; h < 4; ++h)
             dit4(v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3], w1, w2, w3);
@@ -469,7 +538,7 @@ __device__ __forceinline__ void f1k_inverse(float2 (&v)[16], float2 *x, const fl
 #pragma unroll
     for (int m0 = 0; m0 < 4; ++m0) {               // length 64
         const int j = s + 4 * m0;
-        dit4(v[m0], v[m0 + 4], v[m0 + 8], v[m0 + 12], tw[16 * j], tw[32 * j], tw[48 * j]);
+        dit4(v[m0], v[m0 + 4], v[m0 + 8], v[m0 + 12], tw[960 + j], tw[976 + j], tw[992 + j]);
     }
 #pragma unroll
     for (int m = 0; m < 16; ++m)
@@ -480,7 +549,7 @@ __device__ __forceinline__ void f1k_inverse(float2 (&v)[16], float2 *x, const fl
         v[m] = x[f1k_idx(lane + 64 * m)];
     __builtin_amdgcn_wave_barrier();
     {
-        const float2 w1 = tw[4 * lane], w2 = tw[8 * lane], w3 = tw[12 * lane];   // length 256
+        const float2 w1 = tw[768 + lane], w2 = tw[832 + lane], w3 = tw[896 + lane];   // length 256
 #pragma unroll
         for (int g = 0; g < 4; ++g)
             dit4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3], w1, w2, w3);
@@ -488,7 +557,7 @@ __device__ __forceinline__ void f1k_inverse(float2 (&v)[16], float2 *x, const fl
 #pragma unroll
     for (int m0 = 0; m0 < 4; ++m0) {               // length 1024
         const int j = lane + 64 * m0;
-        dit4(v[m0], v[m0 + 4], v[m0 + 8], v[m0 + 12], tw[j], tw[2 * j], tw[3 * j]);
+        dit4(v[m0], v[m0 + 4], v[m0 + 8], v[m0 + 12], tw[j], tw[256 + j], tw[512 + j]);
     }
 }
 
@@ -569,11 +638,10 @@ f1k_rows_forward_kernel(const float *__restrict__ t, int th, int tw_, const floa
                         float2 *__restrict__ spec_r, int hp)
 {
     __shared__ float2 lds[4 * F1K_LDS];
-    __shared__ float2 twiddle[F1K];                 // LDS copy: gathered reads stay off the memory pipeline
+    __shared__ float2 twiddle[F1K_TW];              // LDS copy: gathered reads stay off the memory pipeline
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int y_block = blockIdx.x * 4 * F1K_ROWS_PER_WAVE, pair = blockIdx.y;   // H is a multiple of 16
-    for (int i = threadIdx.x; i < F1K; i += 256)
-        twiddle[i] = twiddle_table[i];
+    f1k_load_twiddles(twiddle, twiddle_table, threadIdx.x, 256);
     __syncthreads();
     float2 *x = lds + wave * F1K_LDS;
     const float *tbase = t + (int64_t)pair * th * tw_;
@@ -629,11 +697,7 @@ f1k_rows_forward_kernel(const float *__restrict__ t, int th, int tw_, const floa
         if (lane == 0)                  // per-row partial sums; fft_row_sums_kernel adds them up
             reinterpret_cast<double4 *>(row_sums)[(int64_t)pair * H + y] = make_double4(ts, tq, rs, rq);
         f1k_forward(v, x, twiddle, lane);
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                x[f1k_idx(4 * (lane + 64 * u) + e)] = v[4 * u + e];
+        f1k_write_quads(v, x, lane);
         __syncthreads();
         // split z = fft(t + i r) into the two half spectra; item -> (column group, row, half)
         constexpr int GROUPS = F1K / 2 / 4 + 1;             // 129: columns 0 .. 512
@@ -722,11 +786,10 @@ f1k_cols_fused_kernel(float2 *__restrict__ spec_t, const float2 *__restrict__ sp
                       int tiles_per_pair, int total_tiles, const float2 *__restrict__ twiddle_table)
 {
     __shared__ float2 tile[F1K_TILE * F1K_COL];
-    __shared__ float2 twiddle[F1K];                 // LDS copy: gathered reads stay off the memory pipeline
+    __shared__ float2 twiddle[F1K_TW];              // LDS copy: gathered reads stay off the memory pipeline
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float2 *x = tile + wave * F1K_COL;
-    for (int i = threadIdx.x; i < F1K; i += 64 * F1K_TILE)
-        twiddle[i] = twiddle_table[i];
+    f1k_load_twiddles(twiddle, twiddle_table, threadIdx.x, 64 * F1K_TILE);
     const int first = blockIdx.x;
 
     float4 q[F1K_QUADS];
@@ -796,11 +859,10 @@ f1k_rows_inverse_kernel(const float2 *__restrict__ spec, const float *__restrict
                         TOut *__restrict__ out)
 {
     __shared__ float2 lds[4 * F1K_LDS];
-    __shared__ float2 twiddle[F1K];                 // LDS copy: gathered reads stay off the memory pipeline
+    __shared__ float2 twiddle[F1K_TW];              // LDS copy: gathered reads stay off the memory pipeline
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int y0 = 2 * (blockIdx.x * 4 + wave), pair = blockIdx.y;
-    for (int i = threadIdx.x; i < F1K; i += 256)
-        twiddle[i] = twiddle_table[i];
+    f1k_load_twiddles(twiddle, twiddle_table, threadIdx.x, 256);
     __syncthreads();
     if (y0 >= H)
         return;
@@ -842,11 +904,7 @@ f1k_rows_inverse_kernel(const float2 *__restrict__ spec, const float *__restrict
     }
     __builtin_amdgcn_wave_barrier();
     float2 v[16];
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            v[4 * u + e] = x[f1k_idx(4 * (lane + 64 * u) + e)];
+    f1k_read_quads(v, x, lane);
     __builtin_amdgcn_wave_barrier();
     f1k_inverse(v, x, twiddle, lane);
     const float scale = (float)(1.0 / ((double)H * (double)F1K) / (tstd * tn) / rstd);
@@ -886,20 +944,21 @@ extern "C" size_t svamd_xcorr2d_fft_workspace_bytes(int batch, int H, int W)
            align_up((size_t)batch * H * 4 * sizeof(double), 256);
 }
 
-extern "C" int svamd_xcorr2d_fft(const float *tmpl, int th, int tw, const float *region, int H, int W,
-                                 int batch, double min_std, double min_mean_diff, void *out, int out_dtype,
-                                 void *workspace, size_t workspace_bytes, void *stream)
+namespace {
+// LDS limits are per function and per device; raising one is cheap, so it is done
+// before every launch that needs more than the default 64 KB.
+template <typename K>
+hipError_t allow_lds(K kernel, size_t bytes)
 {
-    SV_REQUIRE(tmpl && region && out, SVAMD_ERR_INVALID, "xcorr2d_fft: NULL pointer");
-    SV_REQUIRE(batch > 0 && th > 0 && tw > 0, SVAMD_ERR_INVALID, "xcorr2d_fft: non-positive size");
-    SV_REQUIRE(svamd_fft_supported(H, W), SVAMD_ERR_LIMIT,
-               "xcorr2d_fft: region %dx%d is not a power-of-two shape within 4..%d", H, W, FFT_MAX_N);
-    SV_REQUIRE(out_dtype == SVAMD_F32 || out_dtype == SVAMD_F64, SVAMD_ERR_INVALID,
-               "xcorr2d_fft: output must be float32 or float64");
-    SV_REQUIRE(workspace && (reinterpret_cast<uintptr_t>(workspace) & 255) == 0 &&
-                   workspace_bytes >= svamd_xcorr2d_fft_workspace_bytes(batch, H, W),
-               SVAMD_ERR_WORKSPACE, "xcorr2d_fft: workspace missing, misaligned or too small");
-    hipStream_t st = static_cast<hipStream_t>(stream);
+    return bytes > 48 * 1024 ? hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes)
+                             : hipSuccess;
+}
+
+int fft_correlate(const float *tmpl, int th, int tw, const float *region, int H, int W, int batch,
+                  double min_std, double min_mean_diff, void *out, int out_dtype, void *workspace, int raw,
+                  hipStream_t st)
+{
     const int hp = W / 2 + 16, ncols = W / 2 + 1;   // row pitch: an odd number of 128-byte lines for W = 1024
     const int log2w = ilog2(W), log2h = ilog2(H);
     Carver ws(workspace);
@@ -915,19 +974,10 @@ extern "C" int svamd_xcorr2d_fft(const float *tmpl, int th, int tw, const float 
     SV_LAUNCH_CHECK();
     hipLaunchKernelGGL(twiddle_kernel, dim3((H + 255) / 256), dim3(256), 0, st, tw_h, H);
     SV_LAUNCH_CHECK();
-    const bool fast = H == F1K && W == F1K;   // wavefront-per-transform kernels
+    const bool fast = H == F1K && W == F1K && !raw;   // wavefront-per-transform kernels
     if (fast) {
         hipLaunchKernelGGL(fft_centres_kernel, dim3(batch), dim3(1024), 0, st, tmpl, th, tw, region, H, W, stats);
         SV_LAUNCH_CHECK();
-    }
-    if (!fast) {
-        const int64_t t_elems = (int64_t)th * tw, r_elems = (int64_t)H * W;
-        const int sblocks = (int)std::min<int64_t>(64, (r_elems + 4095) / 4096);
-        hipLaunchKernelGGL(fft_stats_kernel, dim3(sblocks, batch), dim3(256), 0, st, tmpl, t_elems, region,
-                           r_elems, stats);
-        SV_LAUNCH_CHECK();
-    }
-    if (fast) {
         hipLaunchKernelGGL(f1k_rows_forward_kernel, dim3((H + 4 * F1K_ROWS_PER_WAVE - 1) / (4 * F1K_ROWS_PER_WAVE), batch), dim3(256), 0, st, tmpl, th, tw, region, H,
                            stats, row_sums, tw_w, spec_t, spec_r, hp);
         SV_LAUNCH_CHECK();
@@ -954,26 +1004,65 @@ extern "C" int svamd_xcorr2d_fft(const float *tmpl, int th, int tw, const float 
         SV_LAUNCH_CHECK();
         return SVAMD_OK;
     }
-    hipLaunchKernelGGL(fft_rows_forward_kernel, dim3(H, batch), dim3(FFT_THREADS), 0, st, tmpl, th, tw, region,
-                       H, W, log2w, stats, tw_w, spec_t, spec_r, hp);
-    SV_LAUNCH_CHECK();
-    const size_t lds = ((size_t)H * 2 * FFT_COLS + H) * sizeof(float2);
-    static bool raised = false;
-    if (!raised) {
-        SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fft_cols_fused_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        raised = true;
+    if (!raw) {
+        const int64_t t_elems = (int64_t)th * tw, r_elems = (int64_t)H * W;
+        const int sblocks = (int)std::min<int64_t>(64, (r_elems + 4095) / 4096);
+        hipLaunchKernelGGL(fft_stats_kernel, dim3(sblocks, batch), dim3(256), 0, st, tmpl, t_elems, region,
+                           r_elems, stats);
+        SV_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(fft_cols_fused_kernel, dim3((ncols + FFT_COLS - 1) / FFT_COLS, batch),
-                       dim3(FFT_COL_THREADS), lds, st, spec_t, spec_r, H, log2h, ncols, hp, tw_h);
+    const size_t row_lds = (size_t)2 * W * sizeof(float2);
+    SV_HIP(allow_lds(&fft_rows_forward_kernel, row_lds));
+    hipLaunchKernelGGL(fft_rows_forward_kernel, dim3(H, batch), dim3(FFT_THREADS), row_lds, st, tmpl, th, tw,
+                       region, H, W, log2w, stats, tw_w, spec_t, spec_r, hp, raw);
+    SV_LAUNCH_CHECK();
+    const int cols = H <= 1024 ? FFT_COLS : H == 2048 ? 4 : 2;
+    const size_t lds = ((size_t)H * 2 * cols + H) * sizeof(float2);
+    SV_HIP(allow_lds(&fft_cols_fused_kernel, lds));
+    hipLaunchKernelGGL(fft_cols_fused_kernel, dim3((ncols + cols - 1) / cols, batch), dim3(FFT_COL_THREADS), lds,
+                       st, spec_t, spec_r, H, log2h, ncols, hp, cols, tw_h);
     SV_LAUNCH_CHECK();
     dim3 g3((H + 1) / 2, batch);
-    if (out_dtype == SVAMD_F32)
-        hipLaunchKernelGGL((fft_rows_inverse_kernel<float>), g3, dim3(FFT_THREADS), 0, st, spec_t, th, tw, H, W,
-                           log2w, hp, stats, min_std, min_mean_diff, tw_w, static_cast<float *>(out));
-    else
-        hipLaunchKernelGGL((fft_rows_inverse_kernel<double>), g3, dim3(FFT_THREADS), 0, st, spec_t, th, tw, H,
-                           W, log2w, hp, stats, min_std, min_mean_diff, tw_w, static_cast<double *>(out));
+    if (out_dtype == SVAMD_F32) {
+        SV_HIP(allow_lds(&fft_rows_inverse_kernel<float>, row_lds));
+        hipLaunchKernelGGL((fft_rows_inverse_kernel<float>), g3, dim3(FFT_THREADS), row_lds, st, spec_t, th, tw, H,
+                           W, log2w, hp, stats, min_std, min_mean_diff, tw_w, static_cast<float *>(out), raw);
+    } else {
+        SV_HIP(allow_lds(&fft_rows_inverse_kernel<double>, row_lds));
+        hipLaunchKernelGGL((fft_rows_inverse_kernel<double>), g3, dim3(FFT_THREADS), row_lds, st, spec_t, th, tw, H,
+                           W, log2w, hp, stats, min_std, min_mean_diff, tw_w, static_cast<double *>(out), raw);
+    }
     SV_LAUNCH_CHECK();
     return SVAMD_OK;
+}
+}  // namespace
+
+namespace svamd {
+// Plain circular correlation of two P x Q float32 arrays through the FFT kernels:
+// out[k][l] = sum_{m,n} a[m][n] * b[(m + k) mod P][(n + l) mod Q], float32.
+size_t fft_raw_workspace_bytes(int P, int Q) { return svamd_xcorr2d_fft_workspace_bytes(1, P, Q); }
+
+int fft_raw_correlate(const float *a, const float *b, int P, int Q, float *out, void *workspace,
+                      hipStream_t stream)
+{
+    SV_REQUIRE(svamd_fft_supported(P, Q), SVAMD_ERR_LIMIT, "fft: %dx%d is not a supported power-of-two shape", P, Q);
+    return fft_correlate(a, P, Q, b, P, Q, 1, 0.0, 0.0, out, SVAMD_F32, workspace, 1, stream);
+}
+}  // namespace svamd
+
+extern "C" int svamd_xcorr2d_fft(const float *tmpl, int th, int tw, const float *region, int H, int W,
+                                 int batch, double min_std, double min_mean_diff, void *out, int out_dtype,
+                                 void *workspace, size_t workspace_bytes, void *stream)
+{
+    SV_REQUIRE(tmpl && region && out, SVAMD_ERR_INVALID, "xcorr2d_fft: NULL pointer");
+    SV_REQUIRE(batch > 0 && th > 0 && tw > 0, SVAMD_ERR_INVALID, "xcorr2d_fft: non-positive size");
+    SV_REQUIRE(svamd_fft_supported(H, W), SVAMD_ERR_LIMIT,
+               "xcorr2d_fft: region %dx%d is not a power-of-two shape within 4..%d", H, W, FFT_MAX_N);
+    SV_REQUIRE(out_dtype == SVAMD_F32 || out_dtype == SVAMD_F64, SVAMD_ERR_INVALID,
+               "xcorr2d_fft: output must be float32 or float64");
+    SV_REQUIRE(workspace && (reinterpret_cast<uintptr_t>(workspace) & 255) == 0 &&
+                   workspace_bytes >= svamd_xcorr2d_fft_workspace_bytes(batch, H, W),
+               SVAMD_ERR_WORKSPACE, "xcorr2d_fft: workspace missing, misaligned or too small");
+    return fft_correlate(tmpl, th, tw, region, H, W, batch, min_std, min_mean_diff, out, out_dtype, workspace, 0,
+                         static_cast<hipStream_t>(stream));
 }

@@ -34,4 +34,12 @@ int slide_launch(const float *t, int th, int tw, const float *img, int64_t img_p
                  int oh, int ow, int sx, int sy, double *out, float *pack, double *partial,
                  hipStream_t stream, size_t partial_cap = 0);
 
+// fft_xcorr.hip
+// Plain circular correlation of two P x Q float32 arrays (P, Q powers of two within
+// svamd_fft_supported) through the LDS FFT kernels, float32 result:
+//   out[k][l] = sum_{m,n} a[m][n] * b[(m + k) mod P][(n + l) mod Q]
+size_t fft_raw_workspace_bytes(int P, int Q);
+int fft_raw_correlate(const float *a, const float *b, int P, int Q, float *out, void *workspace,
+                      hipStream_t stream);
+
 }  // namespace svamd

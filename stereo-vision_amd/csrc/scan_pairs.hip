@@ -980,21 +980,18 @@ extern "C" int svamd_scan_pairs(const double *tbase, const double *rbase, const 
         const size_t lds = (size_t)slots * slot_floats * sizeof(float);
         const int64_t groups = (npairs + slots - 1) / slots;
         const unsigned fgrid = (unsigned)(groups < (1 << 20) ? groups : (1 << 20));
-        static bool raised4 = false, raised8 = false;
         if (G == 8) {
-            if (lds > 64 * 1024 && !raised8) {
+            if (lds > 64 * 1024) {
                 SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_pairs_f32_kernel<8>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-                raised8 = true;
             }
             hipLaunchKernelGGL((scan_pairs_f32_kernel<8>), dim3(fgrid), dim3(fthreads), lds, st, tbase, rbase, pd, npairs,
                                max_side, slots, tasks_per_slot, slot_floats, t_floats, s_floats, min_std, min_mean_diff,
                                out_max, out_argmax, surfaces, surf_off);
         } else {
-            if (lds > 64 * 1024 && !raised4) {
+            if (lds > 64 * 1024) {
                 SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_pairs_f32_kernel<4>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-                raised4 = true;
             }
             hipLaunchKernelGGL((scan_pairs_f32_kernel<4>), dim3(fgrid), dim3(fthreads), lds, st, tbase, rbase, pd, npairs,
                                max_side, slots, tasks_per_slot, slot_floats, t_floats, s_floats, min_std, min_mean_diff,
@@ -1002,20 +999,18 @@ extern "C" int svamd_scan_pairs(const double *tbase, const double *rbase, const 
         }
     } else {
         const size_t lds = elems * sizeof(double);
-        static bool raised4 = false, raised8 = false;   // the attribute is per function, sticky
+        // the LDS limit is per function and per device: raised before every launch that needs it
         if (w64 == 8) {
-            if (lds > 64 * 1024 && !raised8) {
+            if (lds > 64 * 1024) {
                 SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_pairs_kernel<double, 8>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-                raised8 = true;
             }
             hipLaunchKernelGGL((scan_pairs_kernel<double, 8>), dim3(grid), dim3(threads), lds, st, tbase, rbase, pd,
                                npairs, max_side, min_std, min_mean_diff, out_max, out_argmax, surfaces, surf_off);
         } else {
-            if (lds > 64 * 1024 && !raised4) {
+            if (lds > 64 * 1024) {
                 SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_pairs_kernel<double, 4>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-                raised4 = true;
             }
             hipLaunchKernelGGL((scan_pairs_kernel<double, 4>), dim3(grid), dim3(threads), lds, st, tbase, rbase, pd,
                                npairs, max_side, min_std, min_mean_diff, out_max, out_argmax, surfaces, surf_off);

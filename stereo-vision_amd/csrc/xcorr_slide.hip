@@ -954,6 +954,57 @@ scale_1d_kernel(double *__restrict__ out, int64_t total, double divisor, int use
     out[idx] = v;
 }
 
+// Operands of the zero-padded FFT route of the circular correlation, P x Q each:
+// tpad = the mean-removed template (cropped to mh x mw), zeros elsewhere; ext = the
+// mean-removed region wrapped circularly over eh x ew, zeros elsewhere.  Along a
+// side that is a power of two, eh = rh = P: the transform's own period is the
+// region's.  Along any other side eh = rh + mh - 1 <= P: the circular correlation
+// at size P then equals the region-sized one at every lag k < rh (no template
+// element ever meets the padding or its wrap-around).
+__global__ void __launch_bounds__(256)
+pad_operands_kernel(const void *__restrict__ t, int tdtype, int tw, int mh, int mw, const void *__restrict__ r,
+                    int rdtype, int rh, int rw, int eh, int ew, const Stats *__restrict__ tst,
+                    const Stats *__restrict__ rst, int P, int Q, float *__restrict__ tpad, float *__restrict__ ext)
+{
+    const double tmean = tst->mean, rmean = rst->mean;
+    const int64_t total = (int64_t)P * Q;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int y = (int)(i / Q), x = (int)(i - (int64_t)y * Q);
+        float tv = 0.f, rv = 0.f;
+        if (y < mh && x < mw)
+            tv = (float)(load_as_double(t, tdtype, (int64_t)y * tw + x) - tmean);
+        if (y < eh && x < ew)
+            rv = (float)(load_as_double(r, rdtype, (int64_t)(y % rh) * rw + (x % rw)) - rmean);
+        tpad[i] = tv;
+        ext[i] = rv;
+    }
+}
+
+// out[y][x] (rh x rw, float64) from the top-left corner of the P x Q float32 result:
+// the low-deviation branch's constant surface or raw / (std T * T.size * std R).
+__global__ void __launch_bounds__(256)
+circular_epilogue_f32_kernel(const float *__restrict__ raw, int Q, double *__restrict__ out, int rh, int rw,
+                             double tsize, double min_std, double min_mean_diff, const Stats *__restrict__ tst,
+                             const Stats *__restrict__ rst)
+{
+    const int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)rh * rw)
+        return;
+    if (tst->std < min_std) {
+        out[idx] = fabs(tst->mean - rst->mean) < min_mean_diff ? 1.0 : 0.0;
+        return;
+    }
+    // a constant region: the reference divides zeros by a zero deviation, every element
+    // is NaN (the transforms of an all-zero operand are zero only up to rounding)
+    if (rst->std == 0.0) {
+        out[idx] = NAN;
+        return;
+    }
+    const int y = (int)(idx / rw), x = (int)(idx - (int64_t)y * rw);
+    out[idx] = (double)raw[(int64_t)y * Q + x] / (tst->std * tsize) / rst->std;
+}
+
 }  // namespace svamd
 
 using namespace svamd;
@@ -1064,13 +1115,60 @@ extern "C" int svamd_cross_correlate_2d(const double *tmpl, int th, int tw, cons
 }
 
 // ================================ a2 ==========================================
+// Two routes.  The sliding kernel costs mh * mw * rh * rw products and its float32
+// error does not grow with the shapes.  The FFT route pads both operands to the next
+// powers of two above rh + mh - 1 and rw + mw - 1 (any region shape, circular
+// semantics kept exactly: see pad_operands_kernel) and costs O(P Q log(P Q)); its
+// float32 error is relative to |t| |r|, i.e. it grows like sqrt(region size /
+// template size) on the normalised surface, so it is taken only when the (cropped)
+// template covers at least a quarter of the region - and only when the sliding
+// kernel would need more than SPECTRAL_FFT_MIN_PRODUCTS products.
+namespace {
+constexpr double SPECTRAL_FFT_MIN_PRODUCTS = 2e10;
+
+int next_pow2(int v)
+{
+    int p = 4;
+    while (p < v)
+        p <<= 1;
+    return p;
+}
+
+struct A2Route {
+    bool fft;
+    int mh, mw, P, Q;
+    int eh, ew;       // rows / columns of the wrapped region inside the P x Q operand
+};
+A2Route a2_route(int th, int tw, int rh, int rw)
+{
+    A2Route R;
+    R.mh = th < rh ? th : rh;
+    R.mw = tw < rw ? tw : rw;
+    // a power-of-two side is its own circular size; any other is padded beyond the
+    // template's reach
+    const bool p2h = (rh & (rh - 1)) == 0 && rh >= 4, p2w = (rw & (rw - 1)) == 0 && rw >= 4;
+    R.eh = p2h ? rh : rh + R.mh - 1;
+    R.ew = p2w ? rw : rw + R.mw - 1;
+    R.P = p2h ? rh : next_pow2(R.eh);
+    R.Q = p2w ? rw : next_pow2(R.ew);
+    const double products = (double)R.mh * R.mw * (double)rh * rw;
+    R.fft = products >= SPECTRAL_FFT_MIN_PRODUCTS && 4.0 * R.mh * R.mw >= (double)rh * rw &&
+            svamd_fft_supported(R.P, R.Q);
+    return R;
+}
+}  // namespace
+
 extern "C" size_t svamd_cross_correlate_2d_spectral_workspace_bytes(int th, int tw, int rh, int rw)
 {
     if (th <= 0 || tw <= 0 || rh <= 0 || rw <= 0)
         return 0;
-    const int mh = th < rh ? th : rh, mw = tw < rw ? tw : rw;
+    const A2Route R = a2_route(th, tw, rh, rw);
+    const size_t common = 2 * 256 + align_up(stats_scratch_doubles() * 8, 256);
+    if (R.fft)
+        return common + 3 * align_up((size_t)R.P * R.Q * 4, 256) + align_up(fft_raw_workspace_bytes(R.P, R.Q), 256);
+    const int mh = R.mh, mw = R.mw;
     const size_t epitch = align_up((size_t)(rw + mw - 1), 4);
-    return 2 * 256 + align_up(stats_scratch_doubles() * 8, 256) + align_up((size_t)mh * mw * 4, 256) + align_up((size_t)(rh + mh - 1) * epitch * 4, 256) +
+    return common + align_up((size_t)mh * mw * 4, 256) + align_up((size_t)(rh + mh - 1) * epitch * 4, 256) +
            align_up(slide_pack_floats(mh, mw) * 4, 256) + align_up(slide_partial_doubles(mw, rh, rw) * 8, 256);
 }
 
@@ -1090,22 +1188,38 @@ extern "C" int svamd_cross_correlate_2d_spectral(const void *tmpl, int tmpl_dtyp
                SVAMD_ERR_WORKSPACE,
                "cross_correlate_2d_spectral: workspace missing, misaligned or too small");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int mh = th < rh ? th : rh, mw = tw < rw ? tw : rw;
-    const int eh = rh + mh - 1, ew = rw + mw - 1;
-    const int64_t epitch = (int64_t)align_up((size_t)ew, 4);
+    const A2Route R = a2_route(th, tw, rh, rw);
+    const int mh = R.mh, mw = R.mw;
 
     Carver ws(workspace);
     Stats *tst = ws.take<Stats>(1);
     Stats *rst = ws.take<Stats>(1);
     double *sscr = ws.take<double>(stats_scratch_doubles());
+    int rc;
+    if ((rc = stats_launch(tmpl, tmpl_dtype, th, tw, tw, false, tst, sscr, st)) != SVAMD_OK) return rc;
+    if ((rc = stats_launch(region, region_dtype, rh, rw, rw, false, rst, sscr, st)) != SVAMD_OK) return rc;
+    const int64_t total = (int64_t)rh * rw;
+    if (R.fft) {
+        const size_t n = (size_t)R.P * R.Q;
+        float *tpad = ws.take<float>(n);
+        float *ext = ws.take<float>(n);
+        float *raw = ws.take<float>(n);
+        void *fws = ws.take<unsigned char>(fft_raw_workspace_bytes(R.P, R.Q));
+        hipLaunchKernelGGL(pad_operands_kernel, dim3(grid_for((int64_t)n)), dim3(256), 0, st, tmpl, tmpl_dtype, tw,
+                           mh, mw, region, region_dtype, rh, rw, R.eh, R.ew, tst, rst, R.P, R.Q, tpad, ext);
+        SV_LAUNCH_CHECK();
+        if ((rc = fft_raw_correlate(tpad, ext, R.P, R.Q, raw, fws, st)) != SVAMD_OK) return rc;
+        hipLaunchKernelGGL(circular_epilogue_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                           raw, R.Q, out, rh, rw, (double)th * (double)tw, min_std, min_mean_diff, tst, rst);
+        SV_LAUNCH_CHECK();
+        return SVAMD_OK;
+    }
+    const int eh = rh + mh - 1, ew = rw + mw - 1;
+    const int64_t epitch = (int64_t)align_up((size_t)ew, 4);
     float *tp = ws.take<float>((size_t)mh * mw);
     float *ext = ws.take<float>((size_t)eh * epitch);
     float *pack = ws.take<float>(slide_pack_floats(mh, mw));
     double *partial = ws.take<double>(slide_partial_doubles(mw, rh, rw));
-
-    int rc;
-    if ((rc = stats_launch(tmpl, tmpl_dtype, th, tw, tw, false, tst, sscr, st)) != SVAMD_OK) return rc;
-    if ((rc = stats_launch(region, region_dtype, rh, rw, rw, false, rst, sscr, st)) != SVAMD_OK) return rc;
     // template minus its mean, cropped top-left to the region's shape
     hipLaunchKernelGGL(prep_template_kernel, dim3(grid_for((int64_t)mh * mw)), dim3(256), 0, st, tmpl,
                        tmpl_dtype, th, tw, (int64_t)tw, mh, mw, tst, tp);
@@ -1116,7 +1230,6 @@ extern "C" int svamd_cross_correlate_2d_spectral(const void *tmpl, int tmpl_dtyp
     SV_LAUNCH_CHECK();
     if ((rc = slide_launch(tp, mh, mw, ext, epitch, eh, ew, rh, rw, 1, 1, out, pack, partial, st)) != SVAMD_OK)
         return rc;
-    const int64_t total = (int64_t)rh * rw;
     hipLaunchKernelGGL(circular_epilogue_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
                        out, total, (double)th * (double)tw, min_std, min_mean_diff, tst, rst);
     SV_LAUNCH_CHECK();

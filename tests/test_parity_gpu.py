@@ -180,6 +180,41 @@ def test_spectral_large_shapes_vs_oracle(mods, oracle, tshape, rshape):
     assert_surface_close(out, oracle.cross_correlate_2d_spectral(t, r), SURFACE_TOL, 'large circular')
 
 
+@pytest.mark.parametrize('tshape,rshape', [
+    ((2048, 2048), (2048, 2048)),       # power-of-two sides beyond 1024: the FFT kernels directly
+    ((512, 4096), (512, 4096)),
+    ((1000, 1200), (1000, 1200)),       # any shape: both operands zero-padded to 2048 x 4096
+    ((700, 900), (1000, 1200)),         # template padded to the region (covers half of it)
+    ((1300, 1100), (1000, 800)),        # template cropped to the region
+    ((333, 1500), (333, 1500))])
+def test_spectral_fft_routes_large_and_any_shape(mods, oracle, tshape, rshape):
+    '''Large pairs never fall back to the O(N^2) sliding kernel: power-of-two regions
+    up to 4096 per side run through the FFT kernels, other shapes through FFTs of
+    zero-padded operands that keep the circular semantics of the original shape
+    (correlation_spectral.py:51-54).  Against numpy's float64 FFT evaluation.'''
+    rng = np.random.default_rng(tshape[0] + rshape[1])
+    t, r = rng.random(tshape), rng.random(rshape)
+    out = mods['s'].cross_correlate_2d_spectral(t, r)
+    want = oracle.cross_correlate_2d_spectral_fft(t, r)
+    assert_surface_close(out, want, SURFACE_TOL, f'fft route {tshape} {rshape}')
+    # a planted circular shift is found exactly where it is
+    if tshape == rshape:
+        rolled = np.roll(t, (17, 230), axis=(0, 1))
+        out = mods['s'].cross_correlate_2d_spectral(t, rolled)
+        assert np.unravel_index(np.argmax(out), out.shape) == (17, 230)
+        assert abs(out.max() - 1.0) < 1e-5
+
+
+def test_spectral_fft_route_low_std_and_constant_region(mods):
+    t = np.full((1000, 1200), 3.0)
+    rng = np.random.default_rng(2)
+    r = rng.random((1000, 1200))
+    assert np.all(mods['s'].cross_correlate_2d_spectral(t, r) == 0.0)
+    assert np.all(mods['s'].cross_correlate_2d_spectral(t, t.copy()) == 1.0)
+    with np.errstate(all='ignore'):
+        assert np.isnan(mods['s'].cross_correlate_2d_spectral(r, t)).all()   # 0 / 0 as in the reference
+
+
 def test_spectral_large_low_std_branches(mods):
     t = np.full((70, 70), 3.0)
     r = np.full((80, 90), 3.0)
