@@ -78,19 +78,22 @@ def main():
         print(f'Data read from file {args.depth_input}')
 
     if not args.hide_depth:
-        from matplotlib import cm
-        from matplotlib import pyplot as plt
-        figure = plt.figure()
-        ax = figure.add_subplot(1, 1, 1, projection='3d')
-        x_grid, y_grid = np.meshgrid(range(total_depth_grid.shape[1]), range(total_depth_grid.shape[0]))
-        ax.set_ylim(total_depth_grid.shape[0], 0)
-        ax.plot_surface(x_grid, y_grid, total_depth_grid, cmap=cm.coolwarm)
-        ax.set_xlabel('x')
-        ax.set_ylabel('y')
-        figure = plt.figure()
-        figure.add_subplot(1, 2, 1).imshow(total_depth_grid)
-        figure.add_subplot(1, 2, 2).imshow(total_contributions_grid)
-        plt.show()
+        show_depth(total_depth_grid, total_contributions_grid)
+
+
+def show_depth(depth, contributions):
+    '''The averaged displacement magnitude as a surface (image orientation: row 0 at
+    the back) and, side by side, as an image next to the contribution counts.'''
+    from matplotlib import cm
+    from matplotlib import pyplot as plt
+    rows, cols = depth.shape
+    surface = plt.figure().add_subplot(projection='3d')
+    surface.plot_surface(*np.meshgrid(np.arange(cols), np.arange(rows)), depth, cmap=cm.coolwarm)
+    surface.set(xlabel='x', ylabel='y', ylim=(rows, 0))
+    _, panels = plt.subplots(1, 2)
+    for panel, grid in zip(panels, (depth, contributions)):
+        panel.imshow(grid)
+    plt.show()
 
 
 if __name__ == '__main__':

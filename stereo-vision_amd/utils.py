@@ -76,21 +76,28 @@ def greyscale(path):
     return _greyscale_on_device(np.asarray(image), nan_alpha=False, want_u8=True).cpu().numpy()
 
 
-def max_pos(array: np.ndarray, step_x=1, step_y=1):
+def max_pos(array, step_x=1, step_y=1):
     '''(x, y) position of the first maximum of a 2D array, NaNs ignored, scaled
     by the steps exactly as the reference does (utils.py:17-26: the column is
-    multiplied by step_y and the row by step_x).'''
-    array = np.asarray(array)
+    multiplied by step_y and the row by step_x).  A surface that is still on the
+    device (a torch tensor) is reduced there and one integer comes back; a host
+    array is not worth the round trip and is reduced where it is.'''
     torch = nv.torch_cuda()
-    data = nv.to_device(np.ascontiguousarray(array, dtype=np.float64).ravel())
-    idx = nv.empty(1, torch.int64)
-    nv.call('svamd_nanargmax', nv.ptr(data), data.numel(), nv.ptr(idx), nv.stream_ptr())
-    max_index = int(idx.item())
-    if max_index < 0:
-        raise ValueError('All-NaN slice encountered')
+    if isinstance(array, torch.Tensor):
+        data = array.to(device='cuda', dtype=torch.float64).contiguous()
+        idx = nv.empty(1, torch.int64)
+        nv.call('svamd_nanargmax', nv.ptr(data), data.numel(), nv.ptr(idx), nv.stream_ptr())
+        max_index = int(idx.item())
+        if max_index < 0:
+            raise ValueError('All-NaN slice encountered')
+        width = data.shape[1]
+    else:
+        array = np.asarray(array)
+        max_index = int(np.nanargmax(array))          # raises ValueError when every element is NaN
+        width = array.shape[1]
     return (
-        step_y * (max_index % array.shape[1]),
-        step_x * (max_index // array.shape[1]),
+        step_y * (max_index % width),
+        step_x * (max_index // width),
     )
 
 

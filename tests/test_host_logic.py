@@ -116,3 +116,22 @@ def test_band_scan_input_levels():
     for bad in (levels / 254.0, levels.astype(np.int32), levels / 255.0 + 1e-9):
         with pytest.raises(TypeError):
             band_scan.as_uint8_image(bad)
+
+
+def test_dot_grouping_matches_scipy_labelling():
+    '''find_peaks groups the surviving pixels itself: same boxes, in the same order, as
+    scipy.ndimage.label + find_objects (what the reference calls,
+    sv_calibration.py:131-132); and the dot template is the reference's.'''
+    from scipy import ndimage
+    import sv_calibration as sc
+    rng = np.random.default_rng(0)
+    for density in (0.02, 0.15, 0.5):
+        for _ in range(30):
+            m = rng.random((30, 41)) < density
+            rows, cols = np.nonzero(m)
+            lab, _n = ndimage.label(m)
+            want = [(s[0].start, s[0].stop - 1, s[1].start, s[1].stop - 1) for s in ndimage.find_objects(lab)]
+            assert sc.group_boxes(rows, cols) == want
+    assert sc.group_boxes(np.array([], dtype=int), np.array([], dtype=int)) == []
+    xg, yg = np.meshgrid(np.linspace(-5, 5, 101), np.linspace(-5, 5, 101))
+    assert np.array_equal(np.exp(-(np.power(xg, 2) + np.power(yg, 2))), sc.dot_template())

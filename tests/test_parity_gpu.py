@@ -288,6 +288,45 @@ def test_max_pos(mods):
     assert mods['u'].max_pos(a, 5, 7) == (14, 0)
     with pytest.raises(ValueError):
         mods['u'].max_pos(np.full((2, 2), np.nan))
+    # a surface that is still on the device is reduced there
+    import torch
+    rng = np.random.default_rng(3)
+    big = rng.random((300, 517))
+    big[rng.random(big.shape) < 0.1] = np.nan
+    big[7, 11] = big[200, 3] = 2.0                   # tie: the first one wins
+    dev = torch.from_numpy(big).cuda()
+    assert mods['u'].max_pos(dev, 3, 2) == mods['u'].max_pos(big, 3, 2) == (2 * 11, 3 * 7)
+    with pytest.raises(ValueError):
+        mods['u'].max_pos(torch.full((4, 4), float('nan'), device='cuda'))
+
+
+def test_sat2d_tables(mods):
+    '''svamd_sat2d through the C ABI: exact int64 tables for uint8 pixels (with an
+    offset), float64 tables for float32 / float64 pixels, a pitch wider than the
+    row, against numpy's cumulative sums.'''
+    import torch
+    nv = mods['n']
+    rng = np.random.default_rng(9)
+    for h, w, pitch in ((1, 1, 1), (37, 200, 200), (130, 65, 80), (600, 1031, 1031)):
+        img = rng.integers(0, 256, size=(h, pitch), dtype=np.uint8)
+        for dtype, code, offset, acc in ((np.uint8, nv.U8, 128.0, torch.int64), (np.float32, nv.F32, 0.25, torch.float64),
+                                         (np.float64, nv.F64, -3.5, torch.float64)):
+            src = img.astype(dtype) if dtype == np.uint8 else (img / 7.0).astype(dtype)
+            d = nv.to_device(src)
+            s1, s2 = nv.empty((h + 1, w + 1), acc), nv.empty((h + 1, w + 1), acc)
+            nv.call('svamd_sat2d', nv.ptr(d), code, h, w, pitch, offset, nv.ptr(s1), nv.ptr(s2), nv.stream_ptr())
+            v = src[:, :w].astype(np.float64) - offset
+            want1 = np.zeros((h + 1, w + 1))
+            want2 = np.zeros((h + 1, w + 1))
+            want1[1:, 1:] = np.cumsum(np.cumsum(v, axis=0), axis=1)
+            want2[1:, 1:] = np.cumsum(np.cumsum(v * v, axis=0), axis=1)
+            g1, g2 = s1.cpu().numpy(), s2.cpu().numpy()
+            if dtype == np.uint8:
+                assert np.array_equal(g1, want1.astype(np.int64)) and np.array_equal(g2, want2.astype(np.int64))
+            else:
+                assert np.allclose(g1, want1, rtol=1e-12, atol=1e-9) and np.allclose(g2, want2, rtol=1e-12, atol=1e-9)
+    with pytest.raises(nv.NativeError):
+        nv.call('svamd_sat2d', nv.ptr(d), nv.U8, 4, 4, 4, 0.5, nv.ptr(s1), nv.ptr(s2), nv.stream_ptr())
 
 
 # ---- scans ---------------------------------------------------------------------
