@@ -162,7 +162,7 @@ def config3():
     # device-only time of the pair kernel for the cone scan
     windows, stage_boxes = sv_image_comparison._stage0_windows(left, right, 12, 12, (11, 1), (1, 0), 0)
     batch = sv_image_comparison._StageBatch(left.shape[1], right.shape[1])
-    batch.add_arrays(*stage_boxes)
+    batch.add_arrays(*stage_boxes[:4])
     desc = nv.to_device(batch.desc())
     dl, dr = nv.to_device(left), nv.to_device(right)
     out = nv.empty(desc.shape[0], torch.float64)

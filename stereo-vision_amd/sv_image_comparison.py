@@ -10,6 +10,7 @@ launches (libsvamd: svamd_scan_pairs, svamd_scan_fold).
 '''
 import contextlib
 import gc
+from collections.abc import Sequence
 
 import numpy as np
 
@@ -107,6 +108,7 @@ def _axis_candidates(starts, window, span_hw, count, limit):
     return dict(centres=centres.tolist(), grid=grid.tolist(), rejected=rejected.tolist(),
                 begin=begin.tolist(), end=end.tolist(), own_begin=own_begin.tolist(),
                 own_end=own_end.tolist(), own_rejected=own_rejected.tolist(),
+                centre_array=centres, grid_array=grid,
                 arrays=dict(rejected=rejected, begin=begin, end=end, own_begin=own_begin, own_end=own_end,
                             own_rejected=own_rejected, at_centre=grid == centres[:, None]))
 
@@ -115,7 +117,8 @@ def _stage0_boxes(ax, ay, xs, ys, x_window, y_window, image_width, image_height)
     '''The boxes of _stage0_windows as arrays, without a Python loop over regions:
     template boxes [windows, 4], region boxes [pairs, 4] (x_start, x_end, y_start,
     y_end) in the order _stage0_windows lists the regions, the number of regions per
-    window, and which pair is the window's own position.'''
+    window, which pair is the window's own position, and the regions' centres
+    [pairs, 2].'''
     X, Y = ax['arrays'], ay['arrays']
     ncol, nx = X['begin'].shape
     nrow, ny = Y['begin'].shape
@@ -139,6 +142,14 @@ def _stage0_boxes(ax, ay, xs, ys, x_window, y_window, image_width, image_height)
                         ).reshape(nrow, ncol, ny * nx)
     counts = valid.sum(axis=2).ravel()
     region_boxes = boxes[valid]
+    # the regions' centres, same order (what image_scan reports as the match position)
+    cx = np.empty((nrow, ncol, slots))
+    cy = np.empty((nrow, ncol, slots))
+    cx[:, :, 0] = ax['centre_array'][None, :]
+    cy[:, :, 0] = ay['centre_array'][:, None]
+    cx[:, :, 1:].reshape(nrow, ncol, ny, nx)[...] = ax['grid_array'][None, :, None, :]
+    cy[:, :, 1:].reshape(nrow, ncol, ny, nx)[...] = ay['grid_array'][:, None, :, None]
+    region_centres = np.stack([cx[valid], cy[valid]], axis=1)
     centre = np.zeros(len(region_boxes), dtype=bool)
     first = np.concatenate([[0], np.cumsum(counts)[:-1]])
     own = valid[:, :, 0].ravel()
@@ -148,7 +159,7 @@ def _stage0_boxes(ax, ay, xs, ys, x_window, y_window, image_width, image_height)
     template_boxes[:, :, 1] = np.minimum(xs + x_window, image_width)[None, :]
     template_boxes[:, :, 2] = ys[:, None]
     template_boxes[:, :, 3] = np.minimum(ys + y_window, image_height)[:, None]
-    return template_boxes.reshape(-1, 4), region_boxes, counts, centre
+    return template_boxes.reshape(-1, 4), region_boxes, counts, centre, region_centres
 
 
 @contextlib.contextmanager
@@ -199,31 +210,71 @@ def _stage0_windows(template_image, region_image, x_window, y_window, scheme, sc
                                                         ay['rejected'])]
     x_own = list(zip(ax['own_rejected'], ax['own_begin'], ax['own_end'], ax['centres']))
     y_own = list(zip(ay['own_rejected'], ay['own_begin'], ay['own_end'], ay['centres']))
+    stage_boxes = _stage0_boxes(ax, ay, xs, ys, x_window, y_window, image_width, image_height)
+    counts = stage_boxes[2].tolist()
     windows = {}
     window_id = 0
     for row, y in enumerate(ys.tolist()):
-        y_rej, oy0, oy1, y_centre = y_own[row]
+        own_y = y_own[row]
         y_cand = y_cands[row]
         for column, x in enumerate(xs.tolist()):
-            x_rej, ox0, ox1, x_centre = x_own[column]
-            centre = (x_centre, y_centre)
-            # the window's own position first, then the scheme grid row by row
-            regions = [] if (x_rej or y_rej) else [{'centre': centre, 'size': (ox1 - ox0, oy1 - oy0),
-                                                    'image_slice': region_image[oy0:oy1, ox0:ox1]}]
-            regions += [{'centre': (_x, _y), 'size': (x1 - x0, y1 - y0), 'image_slice': region_image[y0:y1, x0:x1]}
-                        for _y, y0, y1, at_row in y_cand
-                        for _x, x0, x1, at_column in x_cands[column]
-                        if not (at_row and at_column)]
+            own_x = x_own[column]
             windows[window_id] = {
                 'row': row,
                 'column': column,
-                'centre': centre,
+                'centre': (own_x[3], own_y[3]),
                 'size': size,
                 'image_slice': template_image[y:y + y_window, x:x + x_window],
-                'target_regions': regions,
+                'target_regions': _Stage0Regions(region_image, own_x, own_y, x_cands[column], y_cand,
+                                                 counts[window_id]),
             }
             window_id += 1
-    return windows, _stage0_boxes(ax, ay, xs, ys, x_window, y_window, image_width, image_height)
+    return windows, stage_boxes
+
+
+class _Stage0Regions(Sequence):
+    '''The target_regions list of a first-stage window, built when it is first looked
+    at.  A scan holds hundreds of thousands of regions, each a dict with a view of
+    the region image; sequence_scan itself works from the box arrays and never
+    needs them, so they cost nothing unless the caller (plots, image_scan on a
+    returned window) reads them.  Behaves as the list it stands for: length,
+    indexing, slicing, iteration, comparison with a list.'''
+    __slots__ = ('_image', '_own_x', '_own_y', '_x_cand', '_y_cand', '_count', '_items')
+
+    def __init__(self, region_image, own_x, own_y, x_cand, y_cand, count):
+        self._image, self._own_x, self._own_y = region_image, own_x, own_y
+        self._x_cand, self._y_cand, self._count, self._items = x_cand, y_cand, count, None
+
+    def _list(self):
+        if self._items is None:
+            image = self._image
+            x_rej, ox0, ox1, x_centre = self._own_x
+            y_rej, oy0, oy1, y_centre = self._own_y
+            # the window's own position first, then the scheme grid row by row
+            items = [] if (x_rej or y_rej) else [{'centre': (x_centre, y_centre), 'size': (ox1 - ox0, oy1 - oy0),
+                                                  'image_slice': image[oy0:oy1, ox0:ox1]}]
+            items += [{'centre': (_x, _y), 'size': (x1 - x0, y1 - y0), 'image_slice': image[y0:y1, x0:x1]}
+                      for _y, y0, y1, at_row in self._y_cand
+                      for _x, x0, x1, at_column in self._x_cand
+                      if not (at_row and at_column)]
+            assert len(items) == self._count
+            self._items = items
+        return self._items
+
+    def __len__(self):
+        return self._count
+
+    def __getitem__(self, index):
+        return self._list()[index]
+
+    def __iter__(self):
+        return iter(self._list())
+
+    def __eq__(self, other):
+        return self._list() == (other._list() if isinstance(other, _Stage0Regions) else other)
+
+    def __repr__(self):
+        return repr(self._list())
 
 
 def whole_image_search_regions(template_image, region_image, x_window, y_window,
@@ -514,19 +565,27 @@ def _sequence_scan(left_image, right_image, scan_config):
                 window_info['stage_centres'] = [window_info['centre']]
                 window_info['stage_sizes'] = [window_info['size']]
             batch = _StageBatch(image_width, right_image.shape[1])
-            batch.add_arrays(*stage_boxes)
+            batch.add_arrays(*stage_boxes[:4])
             if batched and batch.max_side() <= nv.PAIR_MAX_SIDE:
                 best_pair, best_val = batch.run(*resident(), threshold)
+                # the selected region's centre straight from the centre array: the region
+                # dicts themselves are built only if somebody reads them
+                region_centres = stage_boxes[4]
+                matched = best_pair >= 0
+                chosen = region_centres[np.where(matched, best_pair, 0)].tolist()
+                values = best_val.tolist()
+                log_all = LOG_WINDOW_SUMMARY == True          # noqa: E712 (the reference compares this way)
                 for i, (window_id, window_info) in enumerate(windows.items()):
                     centre = window_info['centre']
-                    if best_pair[i] < 0:
-                        pos, val = centre, 0
+                    if matched[i]:
+                        pos, val = tuple(chosen[i]), values[i]
                     else:
-                        local = int(best_pair[i]) - batch.offsets[i]
-                        pos, val = window_info['target_regions'][local]['centre'], float(best_val[i])
-                    _log_summary(window_id, centre, val, pos)
-                    window_info['dp_x'] = pos[0] - centre[0]
-                    window_info['dp_y'] = pos[1] - centre[1]
+                        pos, val = centre, 0
+                    dp_x, dp_y = pos[0] - centre[0], pos[1] - centre[1]
+                    if log_all or dp_x != 0 or dp_y != 0:
+                        _log_summary(window_id, centre, val, pos)
+                    window_info['dp_x'] = dp_x
+                    window_info['dp_y'] = dp_y
             else:
                 for window_id, window_info in windows.items():
                     pos, _ = _image_scan_pairwise(window_info, window_id, threshold)
