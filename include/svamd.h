@@ -186,7 +186,7 @@ int svamd_scan_fold(const double *corr_max, const uint8_t *is_centre, const uint
  * these images into this workspace (e.g. one prepare, then one scan per row
  * shard).  Limits: win_w * win_h <= 1024 (exact float32 accumulation);
  * stride_x == 1; win_h rows of a 256-window-wide tile must fit in LDS (about 70
- * rows for narrow windows).  Window widths 7, 11, 15, 21 and 31 have fully unrolled kernels;
+ * rows for narrow windows).  Window widths 7, 11, 15, 21, 25 and 31 have fully unrolled kernels;
  * any other width runs through a kernel that takes it at run time. */
 size_t svamd_band_scan_u8_workspace_bytes(int H, int W, int win_w, int win_h);
 

@@ -14,7 +14,7 @@ import _native as nv
 import sharding
 import sv_image_comparison as _svic
 
-WINDOW_WIDTHS = (7, 11, 15, 21, 31)    # widths with a fully unrolled kernel; others take the run-time-width one
+WINDOW_WIDTHS = (7, 11, 15, 21, 25, 31)   # widths with a fully unrolled kernel; others take the run-time-width one
 
 
 def as_uint8_image(image):

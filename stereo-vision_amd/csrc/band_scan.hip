@@ -385,48 +385,51 @@ struct LaneState {
     int arg[BAND_X];
 };
 
-// Turns the D accumulators of each window into scores and feeds the selection.
-// k0: offset index (0 .. nd-1) of acc[.][0]; centre_pass: this pass evaluates the
-// centre offset ahead of the ascending sweep (selection-rule mode only).
-template <int D>
-__device__ __forceinline__ void finish_pass(const BandGeom &g, const float2v (&acc)[BAND_X / 2][D], int k0,
-                                            int kend, bool centre_pass, int wy, int xbase,
-                                            const int32_t *__restrict__ wsum_l,
-                                            const double *__restrict__ winv_l,
-                                            const int32_t *__restrict__ wsum_r,
-                                            const double *__restrict__ winv_r, LaneState &st,
-                                            double *__restrict__ scores)
+// Turns the accumulators of offsets D0 .. D0 + DN - 1 (of the D of a pass) of each
+// window into scores and feeds the selection.  k0: offset index (0 .. nd-1) of
+// acc[.][0]; centre_pass: this pass evaluates the centre offset ahead of the
+// ascending sweep (selection-rule mode only).
+template <int D, int D0, int DN>
+__device__ __forceinline__ void finish_range(const BandGeom &g, const float2v (&acc)[BAND_X / 2][D], int k0,
+                                             int kend, bool centre_pass, int wy, int xbase,
+                                             const int32_t *__restrict__ wsum_l,
+                                             const double *__restrict__ winv_l,
+                                             const int32_t *__restrict__ wsum_r,
+                                             const double *__restrict__ winv_r, LaneState &st,
+                                             double *__restrict__ scores)
 {
     const double n = (double)(g.win_w * g.win_h);
     const int64_t srow = (int64_t)wy * g.stride_y * g.nsx;
     // window x at offset d looks at the right-image box xbase + x + d + k0 - max_disp:
-    // BAND_X + D - 1 distinct boxes serve the lane's BAND_X * D evaluations
-    constexpr int NJ = BAND_X + D - 1;
-    double r_sum[NJ], r_inv[NJ];
+    // BAND_X + DN - 1 distinct boxes serve the lane's BAND_X * DN evaluations
+    constexpr int NJ = BAND_X + DN - 1;
+    int32_t r_sum[NJ];
+    double r_inv[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        const int xr = xbase + j + k0 - g.max_disp;
+        const int xr = xbase + D0 + j + k0 - g.max_disp;
         const bool in = xr >= 0 && xr < g.nsx;
-        r_sum[j] = in ? (double)wsum_r[srow + xr] : 0.0;
+        r_sum[j] = in ? wsum_r[srow + xr] : 0;
         r_inv[j] = in ? winv_r[srow + xr] : NAN;       // outside the image: no score
     }
 #pragma unroll
     for (int x = 0; x < BAND_X; ++x) {
         const int xw = xbase + x;
         const bool wvalid = xw < g.nwx;
-        // the window's own statistics are re-read every pass (cache hits) rather than
+        // the window's own statistics are re-read every time (cache hits) rather than
         // held in registers across the accumulation
         const double s1l = wvalid ? (double)wsum_l[srow + xw] : 0.0;   // sum of (L - 128) over the window
         const double invl = wvalid ? winv_l[srow + xw] : NAN;          // 1 / sqrt(A_L)
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
+        for (int dd = 0; dd < DN; ++dd) {
+            const int d = D0 + dd;
             const int k = k0 + d;
             const bool kvalid = k < kend;
             double s = NAN;
             if (wvalid && kvalid) {
                 const float cross = (x & 1) ? acc[x / 2][d].y : acc[x / 2][d].x;
-                const double num = fma(n, (double)cross, -(s1l * r_sum[x + d]));
-                s = num * invl * r_inv[x + d];
+                const double num = fma(n, (double)cross, -(s1l * (double)r_sum[x + dd]));
+                s = num * invl * r_inv[x + dd];
             }
             if (scores && wvalid && kvalid)
                 scores[((int64_t)wy * g.nwx + xw) * g.nd + k] = s;
@@ -449,6 +452,29 @@ __device__ __forceinline__ void finish_pass(const BandGeom &g, const float2v (&a
                 }
             }
         }
+    }
+}
+
+// The scores of one pass.  Eight offsets are finished four at a time: each half
+// needs the statistics of 7 right-image boxes instead of 11 at once, and half the
+// accumulators are dead before the second half's statistics arrive, which keeps
+// the epilogue inside the register budget the accumulation loop leaves (every
+// window still sees its offsets in ascending order).
+template <int D>
+__device__ __forceinline__ void finish_pass(const BandGeom &g, const float2v (&acc)[BAND_X / 2][D], int k0,
+                                            int kend, bool centre_pass, int wy, int xbase,
+                                            const int32_t *__restrict__ wsum_l,
+                                            const double *__restrict__ winv_l,
+                                            const int32_t *__restrict__ wsum_r,
+                                            const double *__restrict__ winv_r, LaneState &st,
+                                            double *__restrict__ scores)
+{
+    if constexpr (D == 8) {
+        finish_range<D, 0, 4>(g, acc, k0, kend, centre_pass, wy, xbase, wsum_l, winv_l, wsum_r, winv_r, st, scores);
+        __builtin_amdgcn_sched_barrier(0);
+        finish_range<D, 4, 4>(g, acc, k0, kend, centre_pass, wy, xbase, wsum_l, winv_l, wsum_r, winv_r, st, scores);
+    } else {
+        finish_range<D, 0, D>(g, acc, k0, kend, centre_pass, wy, xbase, wsum_l, winv_l, wsum_r, winv_r, st, scores);
     }
 }
 
@@ -722,7 +748,7 @@ extern "C" int svamd_band_scan_u8(const uint8_t *left, const uint8_t *right, int
     // Tile geometry.  Row pitches carry 4 floats of slack because the last
     // 4-wide LDS read of a lane may extend past the columns it uses.  As many
     // offsets as fit in LDS are staged per pass over the right image.
-    const bool tuned = win_w == 7 || win_w == 11 || win_w == 15 || win_w == 21 || win_w == 31;
+    const bool tuned = win_w == 7 || win_w == 11 || win_w == 15 || win_w == 21 || win_w == 25 || win_w == 31;
     const int slack = tuned ? 4 : 12;   // the run-time-width row walk reads up to three quads ahead
     g.lpitch = (int)align_up((size_t)(BAND_TX + win_w - 1), 4) + slack;
     size_t lds = 0;
@@ -765,6 +791,7 @@ extern "C" int svamd_band_scan_u8(const uint8_t *left, const uint8_t *right, int
         SV_BAND_CASE(11);
         SV_BAND_CASE(15);
         SV_BAND_CASE(21);
+        SV_BAND_CASE(25);
         SV_BAND_CASE(31);
     default:   // any other width: the kernel that takes it at run time
         return band_launch<0>(g, lds, grid, st, left, right, wl, il, wr, ir, out_disp, out_val, scores);
