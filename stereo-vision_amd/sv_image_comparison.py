@@ -370,6 +370,17 @@ def _select_local(tbase, rbase, desc, is_centre, skip, win_off, threshold, max_s
                 pairs(sub, int(redo.size), nv.ACC_F64, exact)
                 corr.index_copy_(0, d_redo, exact)
                 fold()
+    if SCAN_PRECISION == 'mixed' and npairs:
+        # The value reported for a window (printed, and compared between the partitions
+        # of a later stage) is its selected pair's maximum: re-evaluated in float64, so
+        # that it does not carry the float32 accumulation's last digits.
+        matched = (best_pair >= 0).nonzero().squeeze(1)
+        if matched.numel():
+            chosen = best_pair.index_select(0, matched)
+            sub = d_desc.view(-1, 8).index_select(0, chosen).contiguous()
+            exact = nv.empty(int(chosen.numel()), torch.float64)
+            pairs(sub, int(chosen.numel()), nv.ACC_F64, exact)
+            best_val.index_copy_(0, matched, exact)
     return best_pair.cpu().numpy(), best_val.cpu().numpy()
 
 

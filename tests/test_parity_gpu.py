@@ -404,7 +404,7 @@ def test_image_scan_values_and_log(mods, capsys):
         pos, val = v.image_scan(windows[wid], wid, cfg['correlation_threshold'])
         want = calls[wid]
         assert (pos[0], pos[1]) == (want[1], want[2])
-        assert abs(val - want[3]) < SURFACE_TOL
+        assert abs(val - want[3]) < 1e-11           # the selected pair's value is re-evaluated in float64
     out = capsys.readouterr().out
     assert out.count('Window ') == len(moved)
     assert f'Window {moved[0]}: centre at {windows[moved[0]]["centre"]}, max correlation of' in out
