@@ -521,6 +521,7 @@ struct SlideGeom {
     int64_t pitch;
     int waves, grows, rowlen;
     int nchunks, chunks_per_slice;   // template-column chunks, and how many of them a workgroup sums itself
+    int row_slices, rows_per_slice;  // template rows are cut into this many runs, one per grid slice
 };
 
 // Packed template: for every row m, T0 = (t[m][0..tw-1], 0...) and T1 = (0, t[m][0..tw-1], 0...),
@@ -580,8 +581,11 @@ slide_tiled_kernel(SlideGeom g, const float *__restrict__ tpk, const float *__re
     const int i0 = blockIdx.y * g.waves;
     const int i = i0 + wave;
     const bool has_row = i < g.oh;
-    const int r_first = i0 * g.sy;
-    const int r_end = (min(i0 + g.waves, g.oh) - 1) * g.sy + g.th;   // exclusive
+    // grid slice -> (run of template-column chunks, run of template rows)
+    const int zr = blockIdx.z % g.row_slices, zc = blockIdx.z / g.row_slices;
+    const int mb = zr * g.rows_per_slice, me = min(mb + g.rows_per_slice, g.th);
+    const int r_first = i0 * g.sy + mb;
+    const int r_end = (min(i0 + g.waves, g.oh) - 1) * g.sy + me;   // exclusive
     const int nsteps = (r_end - r_first + g.grows - 1) / g.grows;
     const int qpr = g.rowlen / 4, total_q = g.grows * qpr;
 
@@ -622,7 +626,7 @@ slide_tiled_kernel(SlideGeom g, const float *__restrict__ tpk, const float *__re
     double de[4] = {}, dodd[4] = {};
     int pending = 0;
 
-    const int ch_begin = blockIdx.z * g.chunks_per_slice;
+    const int ch_begin = zc * g.chunks_per_slice;
     const int ch_end = min(ch_begin + g.chunks_per_slice, g.nchunks);
     for (int ch = ch_begin; ch < ch_end; ++ch) {
     n0 = ch * ST_CHUNK;
@@ -638,7 +642,7 @@ slide_tiled_kernel(SlideGeom g, const float *__restrict__ tpk, const float *__re
         for (int rr = 0; rr < g.grows; ++rr) {
             const int r = r_first + step * g.grows + rr;
             const int m = r - i * g.sy;
-            if (!has_row || r >= r_end || m < 0 || m >= g.th)
+            if (!has_row || r >= r_end || m < mb || m >= me)
                 continue;                                     // wave-uniform
             const float *row = buf + rr * g.rowlen;
             const float *t0 = tpk + ((int64_t)m * 2) * g.lp + n0;
@@ -724,10 +728,23 @@ size_t slide_pack_floats(int th, int tw)
     return ((size_t)th * 2 + SS_ROWS) * lp;
 }
 
+// Grid slices of the unit-stride kernel: runs of template-column chunks (wide
+// templates) times runs of template rows (outputs too few to fill the chip on their
+// own), ST_MAX_SLICES partial-sum planes at most.
+static int slide_row_slices(int64_t oh, int64_t ow, int column_slices)
+{
+    const int64_t waves = oh < ST_WAVES ? oh : ST_WAVES;
+    const int64_t tiles = ((ow + ST_TILE - 1) / ST_TILE) * ((oh + waves - 1) / waves) * column_slices;
+    int64_t want = (1024 + tiles - 1) / tiles;
+    if (want > ST_MAX_SLICES / column_slices) want = ST_MAX_SLICES / column_slices;
+    return (int)(want < 1 ? 1 : want);
+}
+
 size_t slide_partial_doubles(int tw, int64_t oh, int64_t ow)
 {
     const int nchunks = slide_chunks(tw);
-    const int planes = nchunks < ST_MAX_SLICES ? nchunks : ST_MAX_SLICES;
+    const int column_planes = nchunks < ST_MAX_SLICES ? nchunks : ST_MAX_SLICES;
+    const int planes = column_planes * slide_row_slices(oh, ow, column_planes);
     return planes > 1 ? (size_t)planes * (size_t)oh * (size_t)ow : 0;
 }
 
@@ -852,7 +869,20 @@ int slide_launch(const float *t, int th, int tw, const float *img, int64_t img_p
     if (want > g.nchunks) want = g.nchunks;
     if (want < 1) want = 1;
     g.chunks_per_slice = (int)((g.nchunks + want - 1) / want);
-    const int nz = (g.nchunks + g.chunks_per_slice - 1) / g.chunks_per_slice;
+    const int nzc = (g.nchunks + g.chunks_per_slice - 1) / g.chunks_per_slice;
+    // few outputs and a tall template: runs of template rows as further grid slices (at
+    // least 8 rows each; the workspace holds slide_partial_doubles() planes)
+    const int column_planes = g.nchunks < ST_MAX_SLICES ? g.nchunks : ST_MAX_SLICES;
+    int row_slices = slide_row_slices(oh, ow, column_planes);
+    if (row_slices > ST_MAX_SLICES / nzc) row_slices = ST_MAX_SLICES / nzc;
+    const size_t cap = partial_cap ? partial_cap : slide_partial_doubles(tw, oh, ow);
+    const int64_t planes_held = (int64_t)(cap / ((size_t)oh * (size_t)ow));
+    if (row_slices > planes_held / nzc) row_slices = (int)(planes_held / nzc);
+    if (row_slices > th / 8) row_slices = th / 8;
+    if (row_slices < 1) row_slices = 1;
+    g.rows_per_slice = (th + row_slices - 1) / row_slices;
+    g.row_slices = (th + g.rows_per_slice - 1) / g.rows_per_slice;
+    const int nz = nzc * g.row_slices;
     dim3 grid((unsigned)gx, (unsigned)gy, nz);
     const size_t lds = (size_t)2 * g.grows * g.rowlen * sizeof(float);
     hipLaunchKernelGGL(slide_tiled_kernel, grid, dim3(g.waves * WAVE), lds, stream, g, pack, img,
