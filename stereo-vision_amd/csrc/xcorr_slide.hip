@@ -498,7 +498,7 @@ pad_template_kernel(const float *__restrict__ tp, int th, int tw, int lp, int pa
 // FMAs.  The template pairs are wave-uniform and arrive through the scalar data
 // path.  The two halves of each accumulator pair are added at the end.
 //
-// A workgroup is up to 8 wavefronts = 8 consecutive output rows of the same
+// A workgroup is up to 4 wavefronts = 4 consecutive output rows of the same
 // column tile and slice of template-column chunks (512 template columns each; a
 // workgroup sums the chunks of its slice itself, slide_reduce_kernel adds the
 // slices).  It walks down
@@ -509,9 +509,12 @@ pad_template_kernel(const float *__restrict__ tp, int th, int tw, int lp, int pa
 // so that the 32-byte lane stride of the window reads is free of bank conflicts.
 constexpr int ST_TILE = 512;     // output columns per wavefront
 constexpr int ST_CHUNK = 512;    // template columns per workgroup
-constexpr int ST_WAVES = 8;      // output rows per workgroup
+constexpr int ST_WAVES = 4;      // output rows per workgroup
 constexpr int ST_ROWS = 4;       // image rows staged per step
-constexpr int ST_STAGE_Q = 6;    // 16-byte pieces a thread stages per step
+// 16-byte pieces a thread stages per step: 4 keep the kernel at 120 registers (four
+// wavefronts per SIMD); 6 (149 registers, three wavefronts) only where 4 pieces per
+// thread cannot hold a single staged row (one-wavefront workgroups of the 1D calls)
+constexpr int ST_STAGE_Q = 4, ST_STAGE_Q_WIDE = 6;
 constexpr int ST_FLUSH = 1024;   // products accumulated in float32 before they are folded into float64
 
 struct SlideGeom {
@@ -569,6 +572,7 @@ __device__ __forceinline__ void slide_group(f2v (&ae)[4], f2v (&ao)[4], const f2
     }
 }
 
+template <int STAGE_Q>
 __global__ void __launch_bounds__(ST_WAVES *WAVE)
 slide_tiled_kernel(SlideGeom g, const float *__restrict__ tpk, const float *__restrict__ img,
                    double *__restrict__ out)
@@ -590,10 +594,10 @@ slide_tiled_kernel(SlideGeom g, const float *__restrict__ tpk, const float *__re
     const int qpr = g.rowlen / 4, total_q = g.grows * qpr;
 
     int n0 = 0;                      // first template column of the chunk in hand
-    f4v stage[ST_STAGE_Q];
+    f4v stage[STAGE_Q];
     auto fetch = [&](int step) {
 #pragma unroll
-        for (int u = 0; u < ST_STAGE_Q; ++u) {
+        for (int u = 0; u < STAGE_Q; ++u) {
             const int q = threadIdx.x + u * nthreads;
             f4v v = {0.f, 0.f, 0.f, 0.f};
             if (q < total_q) {
@@ -612,7 +616,7 @@ slide_tiled_kernel(SlideGeom g, const float *__restrict__ tpk, const float *__re
     };
     auto store = [&](int buf) {
 #pragma unroll
-        for (int u = 0; u < ST_STAGE_Q; ++u) {
+        for (int u = 0; u < STAGE_Q; ++u) {
             const int q = threadIdx.x + u * nthreads;
             if (q < total_q) {
                 const int rr = q / qpr, cq = q - rr * qpr;
@@ -851,9 +855,10 @@ int slide_launch(const float *t, int th, int tw, const float *img, int64_t img_p
     g.waves = oh < ST_WAVES ? oh : ST_WAVES;
     g.rowlen = ST_TILE + (g.lp < ST_CHUNK ? g.lp : ST_CHUNK) + 8;
     const int qpr = g.rowlen / 4;
-    g.grows = ST_STAGE_Q * g.waves * WAVE / qpr;
-    if (g.grows > ST_ROWS) g.grows = ST_ROWS;
     const int64_t rows_touched = (int64_t)(g.waves - 1) * sy + th;
+    const bool wide = ST_STAGE_Q * g.waves * WAVE < qpr;
+    g.grows = (wide ? ST_STAGE_Q_WIDE : ST_STAGE_Q) * g.waves * WAVE / qpr;
+    if (g.grows > ST_ROWS) g.grows = ST_ROWS;
     if (g.grows > rows_touched) g.grows = (int)rows_touched;
     SV_REQUIRE(g.grows >= 1, SVAMD_ERR_LIMIT, "slide: staging does not fit");
     const int64_t gy = ((int64_t)oh + g.waves - 1) / g.waves;
@@ -885,8 +890,12 @@ int slide_launch(const float *t, int th, int tw, const float *img, int64_t img_p
     const int nz = nzc * g.row_slices;
     dim3 grid((unsigned)gx, (unsigned)gy, nz);
     const size_t lds = (size_t)2 * g.grows * g.rowlen * sizeof(float);
-    hipLaunchKernelGGL(slide_tiled_kernel, grid, dim3(g.waves * WAVE), lds, stream, g, pack, img,
-                       nz > 1 ? partial : out);
+    if (wide)
+        hipLaunchKernelGGL(slide_tiled_kernel<ST_STAGE_Q_WIDE>, grid, dim3(g.waves * WAVE), lds, stream, g, pack,
+                           img, nz > 1 ? partial : out);
+    else
+        hipLaunchKernelGGL(slide_tiled_kernel<ST_STAGE_Q>, grid, dim3(g.waves * WAVE), lds, stream, g, pack, img,
+                           nz > 1 ? partial : out);
     SV_LAUNCH_CHECK();
     if (nz > 1) {
         const int64_t total = (int64_t)oh * ow;
