@@ -23,6 +23,42 @@ inline int grid_for(int64_t total, int block = 256, int cap = 65536)
 // ---- statistics ---------------------------------------------------------------
 // One block; two passes (mean, then squared deviations), all in float64, the
 // same two-pass definition numpy's mean/std and nanmean/nanstd use.
+// Element i of an h x w array with row pitch `pitch` (no division when rows are contiguous).
+__device__ __forceinline__ int64_t stats_offset(int64_t i, int w, int64_t pitch)
+{
+    if (pitch == w)
+        return i;
+    const int64_t y = i / w;
+    return y * pitch + (i - y * w);
+}
+
+// Sum and count of a thread's elements first, first + stride, ... < total (of their
+// squared deviations from `mean` when SQUARES), eight loads in flight at a time; a
+// thread adds its elements in index order.
+template <bool SQUARES>
+__device__ __forceinline__ void stats_accumulate(const void *__restrict__ src, int dtype, int w, int64_t pitch,
+                                                 int ignore_nan, int64_t first, int64_t stride, int64_t total,
+                                                 double mean, double &s, double &c)
+{
+    for (int64_t base = first; base < total; base += 8 * stride) {
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int64_t i = base + k * stride;
+            v[k] = i < total ? load_as_double(src, dtype, stats_offset(i, w, pitch)) : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const bool use = base + k * stride < total && (!ignore_nan || !isnan(v[k]));
+            if (use) {
+                const double d = v[k] - mean;
+                s += SQUARES ? d * d : v[k];
+                c += 1.0;
+            }
+        }
+    }
+}
+
 __global__ void __launch_bounds__(1024)
 stats_kernel(const void *__restrict__ src, int dtype, int h, int w, int64_t pitch, int ignore_nan,
              Stats *__restrict__ out)
@@ -30,26 +66,12 @@ stats_kernel(const void *__restrict__ src, int dtype, int h, int w, int64_t pitc
     __shared__ double red[17];
     const int64_t total = (int64_t)h * w;
     double s = 0.0, c = 0.0;
-    for (int64_t i = threadIdx.x; i < total; i += blockDim.x) {
-        int64_t y = i / w, x = i - y * w;
-        double v = load_as_double(src, dtype, y * pitch + x);
-        if (!ignore_nan || !isnan(v)) {
-            s += v;
-            c += 1.0;
-        }
-    }
+    stats_accumulate<false>(src, dtype, w, pitch, ignore_nan, threadIdx.x, blockDim.x, total, 0.0, s, c);
     s = block_sum(s, red);
     c = block_sum(c, red);
     const double mean = s / c;
-    double q = 0.0;
-    for (int64_t i = threadIdx.x; i < total; i += blockDim.x) {
-        int64_t y = i / w, x = i - y * w;
-        double v = load_as_double(src, dtype, y * pitch + x);
-        if (!ignore_nan || !isnan(v)) {
-            double d = v - mean;
-            q += d * d;
-        }
-    }
+    double q = 0.0, c2 = 0.0;
+    stats_accumulate<true>(src, dtype, w, pitch, ignore_nan, threadIdx.x, blockDim.x, total, mean, q, c2);
     q = block_sum(q, red);
     if (threadIdx.x == 0) {
         out->mean = mean;
@@ -73,16 +95,11 @@ stats_partial_kernel(const void *__restrict__ src, int dtype, int h, int w, int6
     const int64_t total = (int64_t)h * w;
     const double mean = pass ? st->mean : 0.0;
     double s = 0.0, c = 0.0;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        int64_t y = i / w, x = i - y * w;
-        double v = load_as_double(src, dtype, y * pitch + x);
-        if (!ignore_nan || !isnan(v)) {
-            const double d = v - mean;
-            s += pass ? d * d : v;
-            c += 1.0;
-        }
-    }
+    const int64_t first = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+    if (pass)
+        stats_accumulate<true>(src, dtype, w, pitch, ignore_nan, first, stride, total, mean, s, c);
+    else
+        stats_accumulate<false>(src, dtype, w, pitch, ignore_nan, first, stride, total, 0.0, s, c);
     s = block_sum(s, red);
     c = block_sum(c, red);
     if (threadIdx.x == 0) {
@@ -508,7 +525,10 @@ pad_template_kernel(const float *__restrict__ tp, int th, int tw, int lp, int pa
 // LDS rows are stored with 16-byte slots swapped inside every other 256-byte line
 // so that the 32-byte lane stride of the window reads is free of bank conflicts.
 constexpr int ST_TILE = 512;     // output columns per wavefront
-constexpr int ST_CHUNK = 512;    // template columns per workgroup
+constexpr int ST_CHUNK = 512;    // template columns per workgroup and chunk
+// ... and for one-wavefront workgroups (a single output row: the 1D calls), so that a
+// staged row of tile + chunk + 8 floats is 4 pieces for each of the 64 lanes
+constexpr int ST_CHUNK_ONE_ROW = 504;
 constexpr int ST_WAVES = 4;      // output rows per workgroup
 constexpr int ST_ROWS = 4;       // image rows staged per step
 // 16-byte pieces a thread stages per step: 4 keep the kernel at 120 registers (four
@@ -523,6 +543,7 @@ struct SlideGeom {
     int eh, ew;            // valid image rows / columns (anything beyond reads as 0)
     int64_t pitch;
     int waves, grows, rowlen;
+    int chunk_cols;                  // template columns per chunk
     int nchunks, chunks_per_slice;   // template-column chunks, and how many of them a workgroup sums itself
     int row_slices, rows_per_slice;  // template rows are cut into this many runs, one per grid slice
 };
@@ -633,8 +654,8 @@ slide_tiled_kernel(SlideGeom g, const float *__restrict__ tpk, const float *__re
     const int ch_begin = zc * g.chunks_per_slice;
     const int ch_end = min(ch_begin + g.chunks_per_slice, g.nchunks);
     for (int ch = ch_begin; ch < ch_end; ++ch) {
-    n0 = ch * ST_CHUNK;
-    const int chunk = min(ST_CHUNK, g.lp - n0);
+    n0 = ch * g.chunk_cols;
+    const int chunk = min(g.chunk_cols, g.lp - n0);
     const int groups = chunk / 8;
     fetch(0);
     store(0);
@@ -707,7 +728,12 @@ slide_reduce_kernel(const double *__restrict__ partial, int nz, int64_t total, d
 }
 
 static int slide_lp(int tw) { return (int)align_up((size_t)tw + 1, 8); }
-static int slide_chunks(int tw) { return (slide_lp(tw) + ST_CHUNK - 1) / ST_CHUNK; }
+static int slide_chunk_cols(int64_t oh) { return oh == 1 ? ST_CHUNK_ONE_ROW : ST_CHUNK; }
+static int slide_chunks(int tw, int64_t oh)
+{
+    const int cols = slide_chunk_cols(oh);
+    return (slide_lp(tw) + cols - 1) / cols;
+}
 constexpr int ST_MAX_SLICES = 16;   // partial-sum planes at most (workgroups sum the chunks of a slice themselves)
 
 // padded template row of the strided kernel: whole pieces (upper bound)
@@ -746,7 +772,7 @@ static int slide_row_slices(int64_t oh, int64_t ow, int column_slices)
 
 size_t slide_partial_doubles(int tw, int64_t oh, int64_t ow)
 {
-    const int nchunks = slide_chunks(tw);
+    const int nchunks = slide_chunks(tw, oh);
     const int column_planes = nchunks < ST_MAX_SLICES ? nchunks : ST_MAX_SLICES;
     const int planes = column_planes * slide_row_slices(oh, ow, column_planes);
     return planes > 1 ? (size_t)planes * (size_t)oh * (size_t)ow : 0;
@@ -851,9 +877,10 @@ int slide_launch(const float *t, int th, int tw, const float *img, int64_t img_p
     SlideGeom g;
     g.th = th; g.tw = tw; g.lp = slide_lp(tw);
     g.oh = oh; g.ow = ow; g.sy = sy; g.eh = eh; g.ew = ew; g.pitch = img_pitch;
-    g.nchunks = slide_chunks(tw);
+    g.chunk_cols = slide_chunk_cols(oh);
+    g.nchunks = slide_chunks(tw, oh);
     g.waves = oh < ST_WAVES ? oh : ST_WAVES;
-    g.rowlen = ST_TILE + (g.lp < ST_CHUNK ? g.lp : ST_CHUNK) + 8;
+    g.rowlen = ST_TILE + (g.lp < g.chunk_cols ? g.lp : g.chunk_cols) + 8;
     const int qpr = g.rowlen / 4;
     const int64_t rows_touched = (int64_t)(g.waves - 1) * sy + th;
     const bool wide = ST_STAGE_Q * g.waves * WAVE < qpr;
@@ -869,7 +896,7 @@ int slide_launch(const float *t, int th, int tw, const float *img, int64_t img_p
     // Template chunks are spread over up to ST_MAX_SLICES grid slices when the output
     // alone does not give the chip enough workgroups; a slice sums its chunks itself.
     const int64_t gx = ((int64_t)ow + ST_TILE - 1) / ST_TILE;
-    int64_t want = (2048 + gx * gy - 1) / (gx * gy);
+    int64_t want = (4096 + gx * gy - 1) / (gx * gy);
     if (want > ST_MAX_SLICES) want = ST_MAX_SLICES;
     if (want > g.nchunks) want = g.nchunks;
     if (want < 1) want = 1;
