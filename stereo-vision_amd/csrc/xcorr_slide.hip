@@ -522,8 +522,11 @@ pad_template_kernel(const float *__restrict__ tp, int th, int tw, int lp, int pa
 // the image rows its outputs touch, staging up to 4 rows at a time in LDS
 // (double-buffered: the next rows are fetched into registers while the current
 // ones are used); image row r serves output row i as template row r - i * sy.
-// LDS rows are stored with 16-byte slots swapped inside every other 256-byte line
-// so that the 32-byte lane stride of the window reads is free of bank conflicts.
+// LDS rows are stored as they are: the 32-byte lane stride of the window reads costs
+// two-way bank conflicts, but then a block's address is the previous one plus a
+// constant (immediate offsets, one address register) - a conflict-free layout with
+// swapped 16-byte slots cost 16 address instructions per 64 packed FMAs and was slower
+// (the LDS is busy a quarter of the time at most).
 constexpr int ST_TILE = 512;     // output columns per wavefront
 constexpr int ST_CHUNK = 512;    // template columns per workgroup and chunk
 // ... and for one-wavefront workgroups (a single output row: the 1D calls), so that a
@@ -567,9 +570,9 @@ pack_template_kernel(const float *__restrict__ tp, int th, int tw, int lp, float
 // The 8 floats at logical columns 8b .. 8b+7 of a staged row, as 4 pairs.
 __device__ __forceinline__ void slide_load_block(const float *row, int b, f2v (&w)[4])
 {
-    const int c = 8 * b, sw = ((b >> 3) & 1) << 2;
-    const f4v lo = *reinterpret_cast<const f4v *>(row + c + sw);
-    const f4v hi = *reinterpret_cast<const f4v *>(row + c + (4 ^ sw));
+    const int c = 8 * b;
+    const f4v lo = *reinterpret_cast<const f4v *>(row + c);
+    const f4v hi = *reinterpret_cast<const f4v *>(row + c + 4);
     w[0] = lo.xy;
     w[1] = lo.zw;
     w[2] = hi.xy;
@@ -641,8 +644,7 @@ slide_tiled_kernel(SlideGeom g, const float *__restrict__ tpk, const float *__re
             const int q = threadIdx.x + u * nthreads;
             if (q < total_q) {
                 const int rr = q / qpr, cq = q - rr * qpr;
-                const int phys = (4 * cq) ^ ((((4 * cq) >> 6) & 1) << 2);
-                *reinterpret_cast<f4v *>(st_lds + (buf * g.grows + rr) * g.rowlen + phys) = stage[u];
+                *reinterpret_cast<f4v *>(st_lds + (buf * g.grows + rr) * g.rowlen + 4 * cq) = stage[u];
             }
         }
     };
@@ -678,6 +680,7 @@ slide_tiled_kernel(SlideGeom g, const float *__restrict__ tpk, const float *__re
             for (; gi + 2 <= groups; gi += 2) {
                 slide_load_block(row, lane + gi + 1, nxt);
                 slide_group(ae, ao, cur, nxt, t0 + 8 * gi, t1 + 8 * gi);
+                __builtin_amdgcn_sched_barrier(0);   // the reload of `cur` stays behind its last use: no register copies
                 slide_load_block(row, lane + gi + 2, cur);
                 slide_group(ae, ao, nxt, cur, t0 + 8 * gi + 8, t1 + 8 * gi + 8);
             }
