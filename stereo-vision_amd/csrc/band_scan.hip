@@ -697,8 +697,10 @@ extern "C" int svamd_band_prepare_u8(const uint8_t *left, const uint8_t *right, 
     BandWs b = band_ws(H, W, win_w, win_h);
     BandTables t = band_tables(workspace, H, W, win_w, win_h);
     int rc;
-    if ((rc = sat2d_launch<uint8_t, uint32_t>(left, H, W, W, 128u, t.s1l, t.s2l, st)) != SVAMD_OK) return rc;
-    if ((rc = sat2d_launch<uint8_t, uint32_t>(right, H, W, W, 128u, t.s1r, t.s2r, st)) != SVAMD_OK) return rc;
+    // (the window statistics are written after the tables: until then their buffer is the tables' scratch)
+    const size_t spare = b.n_stat * sizeof(double);
+    if ((rc = sat2d_launch<uint8_t, uint32_t>(left, H, W, W, 128u, t.s1l, t.s2l, st, t.il, spare)) != SVAMD_OK) return rc;
+    if ((rc = sat2d_launch<uint8_t, uint32_t>(right, H, W, W, 128u, t.s1r, t.s2r, st, t.ir, spare)) != SVAMD_OK) return rc;
     const unsigned sg = (unsigned)((b.n_stat + 255) / 256);
     hipLaunchKernelGGL(window_stats_kernel, dim3(sg), dim3(256), 0, st, t.s1l, t.s2l, H, W, win_w, win_h,
                        t.wl, t.il);

@@ -106,15 +106,101 @@ sat_cols_kernel(int h, int w, TAcc *__restrict__ s1, TAcc *__restrict__ s2)
     }
 }
 
+// Column pass over row blocks, for tables tall enough that one thread per column
+// leaves the chip idle: pass A adds up every (block, column)'s rows, pass B starts each
+// block's scan from the sum of the blocks above it.  Integer tables come out
+// identical to the single-kernel pass (wrapping arithmetic is associative); floating
+// tables differ from it by the rounding of a different summation order.
+template <typename TAcc>
+__global__ void __launch_bounds__(256)
+sat_col_blocksum_kernel(int h, int w, int rows_per_block, const TAcc *__restrict__ s1,
+                        const TAcc *__restrict__ s2, TAcc *__restrict__ sums)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t tp = (int64_t)w + 1;
+    if (x > w)
+        return;
+    const TAcc *t = blockIdx.z == 0 ? s1 : s2;
+    const int y0 = 1 + blockIdx.y * rows_per_block, y1 = min(h, y0 + rows_per_block - 1);
+    TAcc run = TAcc(0);
+    int y = y0;
+    for (; y + 15 <= y1; y += 16) {
+        TAcc v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            v[k] = t[(int64_t)(y + k) * tp + x];
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            run += v[k];
+    }
+    for (; y <= y1; ++y)
+        run += t[(int64_t)y * tp + x];
+    sums[((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * tp + x] = run;
+}
+
+template <typename TAcc>
+__global__ void __launch_bounds__(256)
+sat_cols_blocked_kernel(int h, int w, int rows_per_block, TAcc *__restrict__ s1, TAcc *__restrict__ s2,
+                        const TAcc *__restrict__ sums)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t tp = (int64_t)w + 1;
+    if (x > w)
+        return;
+    TAcc *t = blockIdx.z == 0 ? s1 : s2;
+    const TAcc *above = sums + (int64_t)blockIdx.z * gridDim.y * tp + x;
+    TAcc run = TAcc(0);
+    for (int b = 0; b < (int)blockIdx.y; ++b)
+        run += above[(int64_t)b * tp];
+    const int y0 = 1 + blockIdx.y * rows_per_block, y1 = min(h, y0 + rows_per_block - 1);
+    int y = y0;
+    for (; y + 15 <= y1; y += 16) {
+        TAcc v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            v[k] = t[(int64_t)(y + k) * tp + x];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            run += v[k];
+            t[(int64_t)(y + k) * tp + x] = run;
+        }
+    }
+    for (; y <= y1; ++y) {
+        run += t[(int64_t)y * tp + x];
+        t[(int64_t)y * tp + x] = run;
+    }
+}
+
 template <typename TIn, typename TAcc>
 int sat2d_launch(const TIn *img, int h, int w, int64_t pitch, TAcc offset, TAcc *s1, TAcc *s2,
-                 hipStream_t stream)
+                 hipStream_t stream, void *scratch, size_t scratch_bytes)
 {
     const int waves_per_block = 4;
     dim3 g1((h + 1 + waves_per_block - 1) / waves_per_block);
     hipLaunchKernelGGL((sat_rows_kernel<TIn, TAcc>), g1, dim3(waves_per_block * WAVE), 0, stream,
                        img, h, w, pitch, offset, s1, s2);
     SV_LAUNCH_CHECK();
+    // row blocks: enough of them for ~64 K threads, at least 8 rows each, 32 at most,
+    // and no more than the scratch buffer has room for
+    const int64_t tp = (int64_t)w + 1;
+    int64_t blocks = (65536 + 2 * tp - 1) / (2 * tp);
+    if (blocks > 32) blocks = 32;
+    if (blocks > h / 8) blocks = h / 8;
+    const int64_t room = scratch ? (int64_t)(scratch_bytes / (2 * tp * sizeof(TAcc))) : 0;
+    if (blocks > room) blocks = room;
+    if (blocks >= 2) {
+        const int rows_per_block = (int)((h + blocks - 1) / blocks);
+        const int nb = (h + rows_per_block - 1) / rows_per_block;
+        dim3 g((unsigned)((tp + 255) / 256), nb, 2);
+        TAcc *sums = static_cast<TAcc *>(scratch);
+        hipLaunchKernelGGL((sat_col_blocksum_kernel<TAcc>), g, dim3(256), 0, stream, h, w, rows_per_block, s1, s2,
+                           sums);
+        SV_LAUNCH_CHECK();
+        hipLaunchKernelGGL((sat_cols_blocked_kernel<TAcc>), g, dim3(256), 0, stream, h, w, rows_per_block, s1, s2,
+                           sums);
+        SV_LAUNCH_CHECK();
+        return SVAMD_OK;
+    }
     dim3 g2((w + 1 + 255) / 256, 2);
     hipLaunchKernelGGL((sat_cols_kernel<TAcc>), g2, dim3(256), 0, stream, h, w, s1, s2);
     SV_LAUNCH_CHECK();
@@ -122,14 +208,39 @@ int sat2d_launch(const TIn *img, int h, int w, int64_t pitch, TAcc offset, TAcc 
 }
 
 template int sat2d_launch<uint8_t, uint32_t>(const uint8_t *, int, int, int64_t, uint32_t, uint32_t *,
-                                             uint32_t *, hipStream_t);
+                                             uint32_t *, hipStream_t, void *, size_t);
 template int sat2d_launch<uint8_t, int64_t>(const uint8_t *, int, int, int64_t, int64_t, int64_t *,
-                                            int64_t *, hipStream_t);
+                                            int64_t *, hipStream_t, void *, size_t);
 template int sat2d_launch<float, double>(const float *, int, int, int64_t, double, double *, double *,
-                                         hipStream_t);
+                                         hipStream_t, void *, size_t);
 template int sat2d_launch<double, double>(const double *, int, int, int64_t, double, double *, double *,
-                                          hipStream_t);
+                                          hipStream_t, void *, size_t);
 
+}  // namespace svamd
+
+namespace svamd {
+int sat2d_any(const void *img, int dtype, int h, int w, int64_t pitch, double offset, void *s1, void *s2,
+              hipStream_t st, void *scratch, size_t scratch_bytes)
+{
+    switch (dtype) {
+    case SVAMD_U8:
+        SV_REQUIRE(offset == std::floor(offset), SVAMD_ERR_INVALID,
+                   "svamd_sat2d: offset must be integral for uint8 input");
+        return sat2d_launch<uint8_t, int64_t>(static_cast<const uint8_t *>(img), h, w, pitch,
+                                              (int64_t)offset, static_cast<int64_t *>(s1),
+                                              static_cast<int64_t *>(s2), st, scratch, scratch_bytes);
+    case SVAMD_F32:
+        return sat2d_launch<float, double>(static_cast<const float *>(img), h, w, pitch, offset,
+                                           static_cast<double *>(s1), static_cast<double *>(s2), st, scratch,
+                                           scratch_bytes);
+    case SVAMD_F64:
+        return sat2d_launch<double, double>(static_cast<const double *>(img), h, w, pitch, offset,
+                                            static_cast<double *>(s1), static_cast<double *>(s2), st, scratch,
+                                            scratch_bytes);
+    default:
+        SV_REQUIRE(false, SVAMD_ERR_INVALID, "svamd_sat2d: unsupported dtype %d", dtype);
+    }
+}
 }  // namespace svamd
 
 using namespace svamd;
@@ -140,21 +251,6 @@ extern "C" int svamd_sat2d(const void *img, int dtype, int h, int w, int64_t pit
     SV_REQUIRE(img && s1 && s2, SVAMD_ERR_INVALID, "svamd_sat2d: NULL pointer");
     SV_REQUIRE(h > 0 && w > 0 && pitch >= w, SVAMD_ERR_INVALID, "svamd_sat2d: bad shape %dx%d pitch %lld",
                h, w, (long long)pitch);
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    switch (dtype) {
-    case SVAMD_U8:
-        SV_REQUIRE(offset == std::floor(offset), SVAMD_ERR_INVALID,
-                   "svamd_sat2d: offset must be integral for uint8 input");
-        return sat2d_launch<uint8_t, int64_t>(static_cast<const uint8_t *>(img), h, w, pitch,
-                                              (int64_t)offset, static_cast<int64_t *>(s1),
-                                              static_cast<int64_t *>(s2), st);
-    case SVAMD_F32:
-        return sat2d_launch<float, double>(static_cast<const float *>(img), h, w, pitch, offset,
-                                           static_cast<double *>(s1), static_cast<double *>(s2), st);
-    case SVAMD_F64:
-        return sat2d_launch<double, double>(static_cast<const double *>(img), h, w, pitch, offset,
-                                            static_cast<double *>(s1), static_cast<double *>(s2), st);
-    default:
-        SV_REQUIRE(false, SVAMD_ERR_INVALID, "svamd_sat2d: unsupported dtype %d", dtype);
-    }
+    // no workspace in this signature: the column pass runs as one thread per column
+    return sat2d_any(img, dtype, h, w, pitch, offset, s1, s2, static_cast<hipStream_t>(stream), nullptr, 0);
 }

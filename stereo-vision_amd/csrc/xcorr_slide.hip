@@ -1150,9 +1150,11 @@ extern "C" int svamd_cross_correlate_2d(const double *tmpl, int th, int tw, cons
                        SVAMD_F64, th, tw, (int64_t)tw, th, tw, tst, tp);
     SV_LAUNCH_CHECK();
     // table of the centred template (sums over top-left crops); the table of its squares is not used
-    if ((rc = sat2d_launch<float, double>(tp, th, tw, tw, 0.0, tsat, tsat2, st)) != SVAMD_OK) return rc;
-    rc = svamd_sat2d(region, region_dtype, rh, rw, rw, 0.0, s1, s2, stream);
-    if (rc != SVAMD_OK) return rc;
+    // (the extended image is written after the tables: until then its buffer is their scratch)
+    const size_t ext_bytes = L.n_ext * sizeof(float);
+    if ((rc = sat2d_launch<float, double>(tp, th, tw, tw, 0.0, tsat, tsat2, st, ext, ext_bytes)) != SVAMD_OK)
+        return rc;
+    if ((rc = sat2d_any(region, region_dtype, rh, rw, rw, 0.0, s1, s2, st, ext, ext_bytes)) != SVAMD_OK) return rc;
     // The region's mean only serves as the constant the pixels are centred by before
     // they are rounded to float32 (the epilogue puts the window's own mean back): the
     // table's last entry gives it without another pass over the region.
