@@ -10,13 +10,14 @@ namespace svamd {
 // a scratch buffer (any 256-byte aligned device memory that is free until the call's
 // kernels have run; 2 * 32 * (w + 1) table elements are as much as is ever used) tall
 // tables are scanned down their columns in row blocks; without one, by one thread per
-// column.
+// column.  `device_offset`, when given, replaces `offset` by a double read on the device.
 template <typename TIn, typename TAcc>
 int sat2d_launch(const TIn *img, int h, int w, int64_t pitch, TAcc offset, TAcc *s1, TAcc *s2,
-                 hipStream_t stream, void *scratch = nullptr, size_t scratch_bytes = 0);
+                 hipStream_t stream, void *scratch = nullptr, size_t scratch_bytes = 0,
+                 const double *device_offset = nullptr);
 // ... for an image of dtype SVAMD_U8 (int64 tables), SVAMD_F32 or SVAMD_F64 (float64 tables)
 int sat2d_any(const void *img, int dtype, int h, int w, int64_t pitch, double offset, void *s1, void *s2,
-              hipStream_t stream, void *scratch, size_t scratch_bytes);
+              hipStream_t stream, void *scratch, size_t scratch_bytes, const double *device_offset = nullptr);
 
 // xcorr_slide.hip
 // Two-pass mean / population std of an h x w array (NaNs optionally ignored).

@@ -29,8 +29,10 @@ __device__ __forceinline__ TAcc wave_inclusive_scan(TAcc v, int lane)
 template <typename TIn, typename TAcc>
 __global__ void __launch_bounds__(256)
 sat_rows_kernel(const TIn *__restrict__ img, int h, int w, int64_t pitch, TAcc offset,
-                TAcc *__restrict__ s1, TAcc *__restrict__ s2)
+                const double *__restrict__ device_offset, TAcc *__restrict__ s1, TAcc *__restrict__ s2)
 {
+    if (device_offset)                 // an offset the host does not know (a mean computed on the stream)
+        offset = (TAcc)*device_offset;
     const int lane = threadIdx.x & (WAVE - 1);
     const int row = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
     const int64_t tp = (int64_t)w + 1;
@@ -173,12 +175,12 @@ sat_cols_blocked_kernel(int h, int w, int rows_per_block, TAcc *__restrict__ s1,
 
 template <typename TIn, typename TAcc>
 int sat2d_launch(const TIn *img, int h, int w, int64_t pitch, TAcc offset, TAcc *s1, TAcc *s2,
-                 hipStream_t stream, void *scratch, size_t scratch_bytes)
+                 hipStream_t stream, void *scratch, size_t scratch_bytes, const double *device_offset)
 {
     const int waves_per_block = 4;
     dim3 g1((h + 1 + waves_per_block - 1) / waves_per_block);
     hipLaunchKernelGGL((sat_rows_kernel<TIn, TAcc>), g1, dim3(waves_per_block * WAVE), 0, stream,
-                       img, h, w, pitch, offset, s1, s2);
+                       img, h, w, pitch, offset, device_offset, s1, s2);
     SV_LAUNCH_CHECK();
     // row blocks: enough of them for ~64 K threads, at least 8 rows each, 32 at most,
     // and no more than the scratch buffer has room for
@@ -208,19 +210,19 @@ int sat2d_launch(const TIn *img, int h, int w, int64_t pitch, TAcc offset, TAcc 
 }
 
 template int sat2d_launch<uint8_t, uint32_t>(const uint8_t *, int, int, int64_t, uint32_t, uint32_t *,
-                                             uint32_t *, hipStream_t, void *, size_t);
+                                             uint32_t *, hipStream_t, void *, size_t, const double *);
 template int sat2d_launch<uint8_t, int64_t>(const uint8_t *, int, int, int64_t, int64_t, int64_t *,
-                                            int64_t *, hipStream_t, void *, size_t);
+                                            int64_t *, hipStream_t, void *, size_t, const double *);
 template int sat2d_launch<float, double>(const float *, int, int, int64_t, double, double *, double *,
-                                         hipStream_t, void *, size_t);
+                                         hipStream_t, void *, size_t, const double *);
 template int sat2d_launch<double, double>(const double *, int, int, int64_t, double, double *, double *,
-                                          hipStream_t, void *, size_t);
+                                          hipStream_t, void *, size_t, const double *);
 
 }  // namespace svamd
 
 namespace svamd {
 int sat2d_any(const void *img, int dtype, int h, int w, int64_t pitch, double offset, void *s1, void *s2,
-              hipStream_t st, void *scratch, size_t scratch_bytes)
+              hipStream_t st, void *scratch, size_t scratch_bytes, const double *device_offset)
 {
     switch (dtype) {
     case SVAMD_U8:
@@ -228,15 +230,15 @@ int sat2d_any(const void *img, int dtype, int h, int w, int64_t pitch, double of
                    "svamd_sat2d: offset must be integral for uint8 input");
         return sat2d_launch<uint8_t, int64_t>(static_cast<const uint8_t *>(img), h, w, pitch,
                                               (int64_t)offset, static_cast<int64_t *>(s1),
-                                              static_cast<int64_t *>(s2), st, scratch, scratch_bytes);
+                                              static_cast<int64_t *>(s2), st, scratch, scratch_bytes, device_offset);
     case SVAMD_F32:
         return sat2d_launch<float, double>(static_cast<const float *>(img), h, w, pitch, offset,
                                            static_cast<double *>(s1), static_cast<double *>(s2), st, scratch,
-                                           scratch_bytes);
+                                           scratch_bytes, device_offset);
     case SVAMD_F64:
         return sat2d_launch<double, double>(static_cast<const double *>(img), h, w, pitch, offset,
                                             static_cast<double *>(s1), static_cast<double *>(s2), st, scratch,
-                                            scratch_bytes);
+                                            scratch_bytes, device_offset);
     default:
         SV_REQUIRE(false, SVAMD_ERR_INVALID, "svamd_sat2d: unsupported dtype %d", dtype);
     }
@@ -252,5 +254,5 @@ extern "C" int svamd_sat2d(const void *img, int dtype, int h, int w, int64_t pit
     SV_REQUIRE(h > 0 && w > 0 && pitch >= w, SVAMD_ERR_INVALID, "svamd_sat2d: bad shape %dx%d pitch %lld",
                h, w, (long long)pitch);
     // no workspace in this signature: the column pass runs as one thread per column
-    return sat2d_any(img, dtype, h, w, pitch, offset, s1, s2, static_cast<hipStream_t>(stream), nullptr, 0);
+    return sat2d_any(img, dtype, h, w, pitch, offset, s1, s2, static_cast<hipStream_t>(stream), nullptr, 0, nullptr);
 }

@@ -966,6 +966,7 @@ spatial_epilogue_kernel(double *__restrict__ out, int orows, int ocols, int sx, 
     const int64_t tp = (int64_t)rw + 1;
     const TSat a1 = rect_sum(s1, tp, y0, x0, y0 + h, x0 + w);
     const TSat a2 = rect_sum(s2, tp, y0, x0, y0 + h, x0 + w);
+    // integer tables: sums of the pixels; float64 tables: sums of (pixel - c)
     const double rmean = (double)a1 / n;
     double rstd;
     bool flat;
@@ -977,14 +978,23 @@ spatial_epilogue_kernel(double *__restrict__ out, int orows, int ocols, int sx, 
     } else {
         const double m2 = (double)a2 / n;
         const double var = m2 - rmean * rmean;
-        // float64 tables cannot resolve a relative variance below ~1e-12
-        flat = !(var > 1e-12 * m2);
+        // A constant snapshot must come out as NaN, but its variance is a difference of
+        // rounded table entries: anything below the rounding noise of the four corners
+        // involved (64 units in the last place of the largest of them) counts as zero.
+        const double c1 = fmax(fmax(fabs((double)s1[(int64_t)y0 * tp + x0]), fabs((double)s1[(int64_t)y0 * tp + x0 + w])),
+                               fmax(fabs((double)s1[(int64_t)(y0 + h) * tp + x0]),
+                                    fabs((double)s1[(int64_t)(y0 + h) * tp + x0 + w])));
+        const double c2 = fmax(fmax(fabs((double)s2[(int64_t)y0 * tp + x0]), fabs((double)s2[(int64_t)y0 * tp + x0 + w])),
+                               fmax(fabs((double)s2[(int64_t)(y0 + h) * tp + x0]),
+                                    fabs((double)s2[(int64_t)(y0 + h) * tp + x0 + w])));
+        const double noise = 64.0 * 2.220446049250313e-16 * (c2 + 2.0 * fabs(rmean) * c1) / n;
+        flat = !(var > noise);
         rstd = sqrt(var);
     }
     const double tstd = tst->std;
-    const double c = centre_value(rst, region_dtype);
+    const double shift = std::is_integral<TSat>::value ? centre_value(rst, region_dtype) - rmean : -rmean;
     const double tcrop = tsat[(int64_t)h * (tw + 1) + w];
-    double v = (out[idx] + (c - rmean) * tcrop) / ((double)th * (double)tw);
+    double v = (out[idx] + shift * tcrop) / ((double)th * (double)tw);
     if (tstd == 0.0 || flat)
         v = NAN;
     else
@@ -1154,17 +1164,23 @@ extern "C" int svamd_cross_correlate_2d(const double *tmpl, int th, int tw, cons
     const size_t ext_bytes = L.n_ext * sizeof(float);
     if ((rc = sat2d_launch<float, double>(tp, th, tw, tw, 0.0, tsat, tsat2, st, ext, ext_bytes)) != SVAMD_OK)
         return rc;
-    if ((rc = sat2d_any(region, region_dtype, rh, rw, rw, 0.0, s1, s2, st, ext, ext_bytes)) != SVAMD_OK) return rc;
-    // The region's mean only serves as the constant the pixels are centred by before
-    // they are rounded to float32 (the epilogue puts the window's own mean back): the
-    // table's last entry gives it without another pass over the region.
-    if (region_dtype == SVAMD_U8)
+    if (region_dtype == SVAMD_U8) {
+        if ((rc = sat2d_any(region, region_dtype, rh, rw, rw, 0.0, s1, s2, st, ext, ext_bytes)) != SVAMD_OK) return rc;
+        // The region's mean only serves as the constant the pixels are centred by before
+        // they are rounded to float32 (the epilogue puts the window's own mean back): the
+        // exact integer table's last entry gives it without another pass over the region.
         hipLaunchKernelGGL((mean_from_sat_kernel<int64_t>), dim3(1), dim3(64), 0, st,
                            static_cast<const int64_t *>(s1), rh, rw, rst);
-    else
-        hipLaunchKernelGGL((mean_from_sat_kernel<double>), dim3(1), dim3(64), 0, st,
-                           static_cast<const double *>(s1), rh, rw, rst);
-    SV_LAUNCH_CHECK();
+        SV_LAUNCH_CHECK();
+    } else {
+        // Floating pixels: float64 tables of (pixel - region mean).  Tables of the plain
+        // pixels lose a window's variance in the rounding of sums of squares as soon as
+        // the image's mean is large against its deviation.
+        if ((rc = stats_launch(region, region_dtype, rh, rw, rw, false, rst, sscr, st)) != SVAMD_OK) return rc;
+        if ((rc = sat2d_any(region, region_dtype, rh, rw, rw, 0.0, s1, s2, st, ext, ext_bytes, &rst->mean)) !=
+            SVAMD_OK)
+            return rc;
+    }
     hipLaunchKernelGGL(extend_kernel, dim3(grid_for((int64_t)L.n_ext)), dim3(256), 0, st, region,
                        region_dtype, rh, rw, (int64_t)rw, 0, 0, rst, L.eh, L.ew, L.epitch, ext);
     SV_LAUNCH_CHECK();

@@ -137,6 +137,22 @@ def test_spatial_strided_columns_vs_oracle(mods, oracle, tshape, rshape, sx, sy)
     assert_surface_close(got, want, SURFACE_TOL, f'strided float {tshape} over {rshape}')
 
 
+def test_spatial_float_region_with_large_mean(mods, oracle):
+    '''A floating-point region whose mean is far larger than its deviation (1000 +-
+    0.05): the window statistics come from tables of the pixels minus the region
+    mean, so the small variance survives (tables of the plain pixels would round it
+    away: 1e6 against 2.5e-3 in sums of squares).'''
+    rng = np.random.default_rng(77)
+    region = 1000.0 + 0.1 * rng.random((120, 150))
+    template = region[40:65, 60:90].copy()
+    for reg in (region, region.astype(np.float32)):
+        got = quiet(mods['c'].cross_correlate_2d, template, reg, 3, 2)
+        want = oracle.cross_correlate_2d(template, reg.astype(np.float64), 3, 2)
+        assert np.isfinite(got).all()
+        assert_surface_close(got, want, 2e-4 if reg.dtype == np.float32 else SURFACE_TOL, f'large mean {reg.dtype}')
+    assert np.unravel_index(np.argmax(got), got.shape) == (20, 20)
+
+
 def test_spatial_template_exceeds_region(mods):
     with pytest.raises(Exception, match='Dimensions of template must not exceed those of region.'):
         mods['c'].cross_correlate_2d(np.zeros((5, 5)), np.zeros((4, 9), np.uint8))
