@@ -133,7 +133,12 @@ int svamd_cross_correlate_1d_static(const double *v1, const double *v2, int64_t 
                                     double *out, void *stream);
 
 /* ---- a5: cross_correlate_1d_spectral(template, signal) ------------------------
- * correlation_spectral.py:12-30.  out: ns + nt - 1 float64. */
+ * correlation_spectral.py:12-30.  out: ns + nt - 1 float64.  The shorter array
+ * slides over the other (the circular correlation reads the same either way).
+ * Above 2e10 products both 1D functions evaluate the sum through the library's 2D
+ * float32 transforms (the arrays cut into rows: long recordings against snippets,
+ * music_patterns_africa.py:24-45) as long as the two arrays together stay below
+ * 8.3 million samples; the workspace size reflects the route. */
 size_t svamd_cross_correlate_1d_spectral_workspace_bytes(int64_t nt, int64_t ns);
 int svamd_cross_correlate_1d_spectral(const double *tmpl, int64_t nt, const double *signal, int64_t ns,
                                       double *out, void *workspace, size_t workspace_bytes, void *stream);

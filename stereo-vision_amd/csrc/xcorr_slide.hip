@@ -1323,6 +1323,103 @@ extern "C" int svamd_cross_correlate_2d_spectral(const void *tmpl, int tmpl_dtyp
     return SVAMD_OK;
 }
 
+// ---- long 1D correlations through the 2D transforms ---------------------------------
+// raw[k] = sum_{n < nt} t[n] * e[n + k], k < L, over arrays cut into rows of Q samples:
+// with n = i Q + j and k = a Q + b the sample e[n + k] is element (i + a, j + b) of the
+// row image of e when j + b < Q and element (i + a + 1, j + b - Q) otherwise, so
+//     raw[a Q + b] = C[a][b] + C[a + 1][b - Q]
+// where C is the 2D linear correlation of the two row images.  C comes from the circular
+// correlation of P x 2Q arrays whose right halves are zero (column lags -Q < b' < Q never
+// wrap onto data) and whose P >= rows(e) + 2 rows hold every row lag without wrapping.
+// No 1D transform longer than 4096 points and no twiddle pass between the dimensions is
+// needed.  Taken when the sliding kernel would need more than CORR1D_FFT_MIN_PRODUCTS
+// products and the row images fit the transforms (nt + L - 1 <= 4094 x 2048 samples); the
+// float32 error is relative to |t| |e| and stays below 1e-5 of the result's scale for the
+// lengths this admits.
+namespace {
+constexpr double CORR1D_FFT_MIN_PRODUCTS = 2e10;
+struct Corr1dFft {
+    bool ok;
+    int Q, P, W;       // samples per row, rows and columns of the padded arrays
+};
+Corr1dFft corr1d_fft_plan(int64_t nt, int64_t L)
+{
+    Corr1dFft best = {false, 0, 0, 0};
+    if ((double)nt * (double)L < CORR1D_FFT_MIN_PRODUCTS)
+        return best;
+    const int64_t le = L + nt - 1;
+    int64_t best_size = 0;
+    for (int Q = 2; Q <= 2048; Q <<= 1) {
+        const int64_t rows = (le + Q - 1) / Q + 2;
+        if (rows > 4096)
+            continue;
+        int P = 4;
+        while (P < rows)
+            P <<= 1;
+        const int W = 2 * Q;
+        if (!svamd_fft_supported(P, W))
+            continue;
+        const int64_t size = (int64_t)P * W;
+        // the smallest arrays; among equals the squarest
+        if (!best.ok || size < best_size || (size == best_size && std::abs(P - W) < std::abs(best.P - best.W))) {
+            best = {true, Q, P, W};
+            best_size = size;
+        }
+    }
+    return best;
+}
+size_t corr1d_fft_workspace_bytes(const Corr1dFft &f)
+{
+    return f.ok ? 3 * align_up((size_t)f.P * f.W * 4, 256) + align_up(fft_raw_workspace_bytes(f.P, f.W), 256) : 0;
+}
+
+// row images of t (nt samples) and e (le samples), zero elsewhere
+__global__ void __launch_bounds__(256)
+corr1d_rows_kernel(const float *__restrict__ t, int64_t nt, const float *__restrict__ e, int64_t le, int Q,
+                   int W, int64_t total, float *__restrict__ a, float *__restrict__ b)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / W;
+        const int col = (int)(i - row * W);
+        const int64_t n = row * Q + col;
+        a[i] = col < Q && n < nt ? t[n] : 0.0f;
+        b[i] = col < Q && n < le ? e[n] : 0.0f;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+corr1d_combine_kernel(const float *__restrict__ c, int Q, int W, int64_t L, double *__restrict__ out)
+{
+    const int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (k >= L)
+        return;
+    const int64_t a = k / Q;
+    const int b = (int)(k - a * Q);
+    out[k] = (double)c[a * W + b] + (double)c[(a + 1) * W + Q + b];
+}
+
+int corr1d_fft_launch(const Corr1dFft &f, const float *t, int64_t nt, const float *e, int64_t L, double *out,
+                      void *workspace, hipStream_t st)
+{
+    Carver ws(workspace);
+    const size_t elems = (size_t)f.P * f.W;
+    float *a = ws.take<float>(elems);
+    float *b = ws.take<float>(elems);
+    float *c = ws.take<float>(elems);
+    void *fws = ws.take<unsigned char>(fft_raw_workspace_bytes(f.P, f.W));
+    hipLaunchKernelGGL(corr1d_rows_kernel, dim3(grid_for((int64_t)elems)), dim3(256), 0, st, t, nt, e, L + nt - 1,
+                       f.Q, f.W, (int64_t)elems, a, b);
+    SV_LAUNCH_CHECK();
+    int rc;
+    if ((rc = fft_raw_correlate(a, b, f.P, f.W, c, fws, st)) != SVAMD_OK) return rc;
+    hipLaunchKernelGGL(corr1d_combine_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, st, c, f.Q, f.W, L,
+                       out);
+    SV_LAUNCH_CHECK();
+    return SVAMD_OK;
+}
+}  // namespace
+
 // ================================ a3 ==========================================
 extern "C" size_t svamd_cross_correlate_1d_workspace_bytes(int64_t n)
 {
@@ -1330,7 +1427,8 @@ extern "C" size_t svamd_cross_correlate_1d_workspace_bytes(int64_t n)
         return 0;
     return 2 * 256 + align_up(stats_scratch_doubles() * 8, 256) + align_up((size_t)n * 4, 256) + align_up((size_t)(3 * n - 2) * 4, 256) +
            align_up(slide_pack_floats(1, (int)n) * 4, 256) +
-           align_up(slide_partial_doubles((int)n, 1, 2 * n - 1) * 8, 256);
+           align_up(slide_partial_doubles((int)n, 1, 2 * n - 1) * 8, 256) +
+           corr1d_fft_workspace_bytes(corr1d_fft_plan(n, 2 * n - 1));
 }
 
 // The launches of cross_correlate_1d over a workspace of at least
@@ -1355,8 +1453,13 @@ static int xcorr1d_enqueue(const double *v1, const double *v2, int64_t n, int no
     hipLaunchKernelGGL(extend_1d_full_kernel, dim3(grid_for(3 * n - 2)), dim3(256), 0, st, v2, n, s2, ext);
     SV_LAUNCH_CHECK();
     const int64_t total = 2 * n - 1;
-    if ((rc = slide_launch(tp, 1, (int)n, ext, 3 * n - 2, 1, (int)(3 * n - 2), 1, (int)total, 1, 1, out, pack,
-                           partial, st)) != SVAMD_OK)
+    const Corr1dFft fft = corr1d_fft_plan(n, total);
+    if (fft.ok)
+        rc = corr1d_fft_launch(fft, tp, n, ext, total, out, ws.take<unsigned char>(corr1d_fft_workspace_bytes(fft)), st);
+    else
+        rc = slide_launch(tp, 1, (int)n, ext, 3 * n - 2, 1, (int)(3 * n - 2), 1, (int)total, 1, 1, out, pack,
+                          partial, st);
+    if (rc != SVAMD_OK)
         return rc;
     hipLaunchKernelGGL(scale_1d_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, out, total,
                        (double)n, normalised ? 1 : 0, normalised ? 1 : 0, s1, s2);
@@ -1435,10 +1538,12 @@ extern "C" size_t svamd_cross_correlate_1d_spectral_workspace_bytes(int64_t nt, 
     if (ns < nt)
         return common + align_up((size_t)ns * 4, 256) + align_up((size_t)(N + ns - 1) * 4, 256) +
                align_up((size_t)N * 8, 256) + align_up(slide_pack_floats(1, (int)ns) * 4, 256) +
-               align_up(slide_partial_doubles((int)ns, 1, N) * 8, 256);
+               align_up(slide_partial_doubles((int)ns, 1, N) * 8, 256) +
+               corr1d_fft_workspace_bytes(corr1d_fft_plan(ns, N));
     return common + align_up((size_t)nt * 4, 256) + align_up((size_t)(ns + 2 * nt - 2) * 4, 256) +
            align_up(slide_pack_floats(1, (int)nt) * 4, 256) +
-           align_up(slide_partial_doubles((int)nt, 1, N) * 8, 256);
+           align_up(slide_partial_doubles((int)nt, 1, N) * 8, 256) +
+           corr1d_fft_workspace_bytes(corr1d_fft_plan(nt, N));
 }
 
 extern "C" int svamd_cross_correlate_1d_spectral(const double *tmpl, int64_t nt, const double *signal,
@@ -1472,8 +1577,14 @@ extern "C" int svamd_cross_correlate_1d_spectral(const double *tmpl, int64_t nt,
         hipLaunchKernelGGL(extend_1d_template_kernel, dim3(grid_for(N + ns - 1)), dim3(256), 0, st, tmpl, nt, N,
                            N + ns - 1, s1, ext);
         SV_LAUNCH_CHECK();
-        if ((rc = slide_launch(sp, 1, (int)ns, ext, N + ns - 1, 1, (int)(N + ns - 1), 1, (int)N, 1, 1, raw, pack,
-                               partial, st)) != SVAMD_OK)
+        const Corr1dFft fft = corr1d_fft_plan(ns, N);
+        if (fft.ok)
+            rc = corr1d_fft_launch(fft, sp, ns, ext, N, raw, ws.take<unsigned char>(corr1d_fft_workspace_bytes(fft)),
+                                   st);
+        else
+            rc = slide_launch(sp, 1, (int)ns, ext, N + ns - 1, 1, (int)(N + ns - 1), 1, (int)N, 1, 1, raw, pack,
+                              partial, st);
+        if (rc != SVAMD_OK)
             return rc;
         hipLaunchKernelGGL(scale_1d_swapped_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, raw, N,
                            nt, s1, out);
@@ -1490,8 +1601,13 @@ extern "C" int svamd_cross_correlate_1d_spectral(const double *tmpl, int64_t nt,
     hipLaunchKernelGGL(extend_1d_circular_kernel, dim3(grid_for(N + nt - 1)), dim3(256), 0, st, signal, nt,
                        ns, ext);
     SV_LAUNCH_CHECK();
-    if ((rc = slide_launch(tp, 1, (int)nt, ext, N + nt - 1, 1, (int)(N + nt - 1), 1, (int)N, 1, 1, out, pack,
-                           partial, st)) != SVAMD_OK)
+    const Corr1dFft fft = corr1d_fft_plan(nt, N);
+    if (fft.ok)
+        rc = corr1d_fft_launch(fft, tp, nt, ext, N, out, ws.take<unsigned char>(corr1d_fft_workspace_bytes(fft)), st);
+    else
+        rc = slide_launch(tp, 1, (int)nt, ext, N + nt - 1, 1, (int)(N + nt - 1), 1, (int)N, 1, 1, out, pack,
+                          partial, st);
+    if (rc != SVAMD_OK)
         return rc;
     hipLaunchKernelGGL(scale_1d_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, out, N,
                        (double)nt, 1, 0, s1, s1);

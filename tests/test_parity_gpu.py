@@ -292,6 +292,48 @@ def test_1d_spectral_long_template_short_signal(mods, oracle):
     assert int(np.argmax(got)) == int(np.argmax(want))
 
 
+def test_1d_long_arrays_take_the_transform_route(mods):
+    '''Above 2e10 products the 1D correlations leave the sliding kernel for the 2D
+    transforms (arrays cut into rows; raw[aQ + b] = C[a][b] + C[a + 1][b - Q]).  The
+    full outputs against the reference's own formulas evaluated with numpy's float64
+    FFTs (correlation_spectral.py:17-29; correlation.py:59-73 as a linear correlation
+    of the centred, zero-padded-then-centred vectors), within 1e-5 of the scale.'''
+    rng = np.random.default_rng(2024)
+
+    def reference_spectral(template, signal):
+        padded = np.concatenate([np.zeros(template.size - 1), signal])
+        t = (template - template.mean()) / (template.std() * template.size)
+        size = signal.size + template.size - 1
+        return np.real(np.fft.ifft(np.conj(np.fft.fft(t, n=size)) * np.fft.fft(padded, n=size)))
+
+    def reference_1d(v1, v2):
+        n = v1.size
+        a = v1 - v1.mean()
+        b = np.concatenate([np.zeros(n - 1), v2, np.zeros(n - 1)]) - v2.mean()
+        size = 4 * n
+        full = np.real(np.fft.ifft(np.conj(np.fft.fft(a, n=size)) * np.fft.fft(b, n=size)))
+        return full[:2 * n - 1] / n
+
+    # the template slides (nt * N = 3.8e10 products)
+    t, sig = rng.standard_normal(120_000) * 3 + 1, rng.standard_normal(200_000)
+    sig[50_000:170_000] += 0.5 * t
+    got, want = mods['s'].cross_correlate_1d_spectral(t, sig), reference_spectral(t, sig)
+    close_1d(got, want, 'transform route, template slides')
+    assert int(np.argmax(got)) == int(np.argmax(want)) == 50_000 + 120_000 - 1
+    # the shorter signal slides (ns * N = 4e10)
+    long = rng.standard_normal(300_000) * 100
+    snippet = long[123_456:223_456] + 5 * rng.standard_normal(100_000)
+    got, want = mods['s'].cross_correlate_1d_spectral(long, snippet), reference_spectral(long, snippet)
+    close_1d(got, want, 'transform route, signal slides')
+    assert int(np.argmax(got)) == int(np.argmax(want))
+    # cross_correlate_1d, n (2n - 1) = 2.9e10
+    v1 = rng.standard_normal(120_000) + 2
+    v2 = np.roll(v1, 777) + 0.1 * rng.standard_normal(120_000)
+    got, want = quiet(mods['c'].cross_correlate_1d, v1, v2), reference_1d(v1, v2)
+    close_1d(got, want, 'transform route, cross_correlate_1d')
+    assert int(np.argmax(got)) == int(np.argmax(want))
+
+
 def test_1d_unequal_raises(mods):
     with pytest.raises(Exception, match='unequal length'):
         mods['c'].cross_correlate_1d(np.zeros(4), np.zeros(5))
