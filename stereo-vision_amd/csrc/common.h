@@ -78,6 +78,32 @@ __device__ __forceinline__ T wave_sum(T v)
     return v;
 }
 
+// The float64 sum of a wavefront through the vector ALU's lane-shift operands
+// (row_shr 1, 2, 4, 8 inside each row of 16 lanes, then row_bcast 15 and 31 across
+// the rows: the total arrives in lane 63 and is broadcast from there).  Shuffles
+// (ds_bpermute) would occupy the LDS pipeline, which the kernels that call this
+// between their staging phases keep busy already.  Lanes without a source add 0.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_shifted(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+template <>
+__device__ __forceinline__ double wave_sum<double>(double v)
+{
+    v += dpp_shifted<0x111, 0xF>(v);
+    v += dpp_shifted<0x112, 0xF>(v);
+    v += dpp_shifted<0x114, 0xF>(v);
+    v += dpp_shifted<0x118, 0xF>(v);
+    v += dpp_shifted<0x142, 0xA>(v);
+    v += dpp_shifted<0x143, 0xC>(v);
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+
 // Sum over a block of up to 1024 threads; every thread receives the total.
 // `red` points to at least 17 doubles of LDS.
 __device__ __forceinline__ double block_sum(double v, double *red)
