@@ -38,16 +38,43 @@ __device__ __forceinline__ BestNan combine(BestNan a, BestNan b)
     return r;
 }
 
+// A wavefront's best element through lane-shift operands (the steps of wave_sum<double>;
+// a lane without a source combines with itself, which changes nothing); every lane
+// receives the result.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_or_self(int v)
+{
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, false);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ BestNan best_shifted(BestNan v)
+{
+    BestNan n;
+    n.best = __hiloint2double(dpp_or_self<CTRL, ROW_MASK>(__double2hiint(v.best)),
+                              dpp_or_self<CTRL, ROW_MASK>(__double2loint(v.best)));
+    n.arg = dpp_or_self<CTRL, ROW_MASK>(v.arg);
+    n.has_nan = dpp_or_self<CTRL, ROW_MASK>(v.has_nan);
+    return n;
+}
+__device__ __forceinline__ BestNan wave_best_dpp(BestNan v)
+{
+    v = combine(v, best_shifted<0x111, 0xF>(v));
+    v = combine(v, best_shifted<0x112, 0xF>(v));
+    v = combine(v, best_shifted<0x114, 0xF>(v));
+    v = combine(v, best_shifted<0x118, 0xF>(v));
+    v = combine(v, best_shifted<0x142, 0xA>(v));
+    v = combine(v, best_shifted<0x143, 0xC>(v));
+    BestNan r;
+    r.best = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v.best), 63),
+                              __builtin_amdgcn_readlane(__double2loint(v.best), 63));
+    r.arg = __builtin_amdgcn_readlane(v.arg, 63);
+    r.has_nan = __builtin_amdgcn_readlane(v.has_nan, 63);
+    return r;
+}
+
 __device__ __forceinline__ BestNan block_best(BestNan v, double *red_d, int *red_i)
 {
-#pragma unroll
-    for (int o = WAVE / 2; o > 0; o >>= 1) {
-        BestNan n;
-        n.best = __shfl_xor(v.best, o, WAVE);
-        n.arg = __shfl_xor(v.arg, o, WAVE);
-        n.has_nan = __shfl_xor(v.has_nan, o, WAVE);
-        v = combine(v, n);
-    }
+    v = wave_best_dpp(v);
     const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;
     const int nw = blockDim.x / WAVE;
     __syncthreads();
@@ -513,18 +540,7 @@ struct SlotInfo {
 constexpr int PAIR_MAX_SLOTS = 16;
 constexpr int PAIR_FLUSH = 256;     // float32 products per accumulator between float64 folds
 
-__device__ __forceinline__ BestNan wave_best(BestNan v)
-{
-#pragma unroll
-    for (int o = WAVE / 2; o > 0; o >>= 1) {
-        BestNan n;
-        n.best = __shfl_xor(v.best, o, WAVE);
-        n.arg = __shfl_xor(v.arg, o, WAVE);
-        n.has_nan = __shfl_xor(v.has_nan, o, WAVE);
-        v = combine(v, n);
-    }
-    return v;
-}
+__device__ __forceinline__ BestNan wave_best(BestNan v) { return wave_best_dpp(v); }
 
 // Two sums over the workgroup at once (in place): one wavefront needs no LDS round
 // trip, two or four wavefronts exchange their parts through red[0..7].
