@@ -530,6 +530,25 @@ __device__ __forceinline__ int pair_row_swap(int a)
     return ((a >> (G == 4 ? 1 : 2)) & 1) << 2;
 }
 
+// The float64 sum over each row of 16 lanes, delivered to all 16 with the same bits:
+// a butterfly of lane exchanges (neighbours, pairs, mirrored halves of 8, mirrored row)
+// in which both partners of an exchange add the same two numbers.
+template <int CTRL>
+__device__ __forceinline__ double dpp_exchanged(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row16_sum(double v)
+{
+    v += dpp_exchanged<0xB1>(v);      // quad_perm [1, 0, 3, 2]
+    v += dpp_exchanged<0x4E>(v);      // quad_perm [2, 3, 0, 1]
+    v += dpp_exchanged<0x141>(v);     // row_half_mirror
+    v += dpp_exchanged<0x140>(v);     // row_mirror
+    return v;
+}
+
 struct SlotInfo {
     double tmean, rmean, tstd, rstd;
     int th, tw, rh, rw;
@@ -594,7 +613,10 @@ __device__ unsigned long long pair_stamps[8];
 #define PAIR_STAMP(slot) do { } while (0)
 #endif
 
-template <int G>
+// SHARED: several pairs (sides up to 16) share one wavefront and are staged by rows of 16
+// lanes; an instantiation of its own, so that its staging registers do not count against
+// the occupancy of the kernel for larger pairs.
+template <int G, bool SHARED>
 __global__ void __launch_bounds__(4 * WAVE)
 scan_pairs_f32_kernel(const double *__restrict__ tbase, const double *__restrict__ rbase,
                       const PairDesc *__restrict__ desc, int64_t npairs, int max_side, int slots,
@@ -629,6 +651,100 @@ scan_pairs_f32_kernel(const double *__restrict__ tbase, const double *__restrict
 #ifdef SV_PAIR_STAMPS
         unsigned long long stamp_ = clock64();
 #endif
+        if constexpr (SHARED) {
+            // ---- statistics and staging of pairs that share the wavefront: four pairs at a
+            // time, one per row of 16 lanes, a lane owning one column of its pair's template
+            // and then of its region with the column's pixels in registers (sides are 16 at
+            // most here).  Sums run down the column and then across the row of lanes.
+            // Everything a lane can reach is zero before the staging lands on it: pairs walk
+            // the wave-uniform row and column-group counts of the largest pair in the
+            // wavefront, past their own columns and rows, against template zeros - and
+            // 0 * NaN is NaN, so no bit patterns of earlier pairs may be left.  (One
+            // wavefront: its LDS operations complete in order.)
+            {
+                float4 *z = reinterpret_cast<float4 *>(lds);
+                const int n4 = slots * slot_floats / 4;
+                for (int i = lane; i < n4; i += WAVE)
+                    z[i] = float4{0.f, 0.f, 0.f, 0.f};
+            }
+            const int x = lane & 15, row16 = lane >> 4;
+            for (int s0 = 0; s0 < slots; s0 += 4) {
+                const int s = s0 + row16;
+                const int64_t p = base + s;
+                const bool present = s < slots && p < npairs;
+                PairDesc d;
+                d.t_off = d.r_off = 0;
+                d.t_pitch = d.r_pitch = 0;
+                d.t_h = d.t_w = d.r_h = d.r_w = 0;
+                if (present)
+                    d = desc[p];
+                const bool ok = present && pair_desc_ok(d, max_side);
+                const int th = ok ? (int)d.t_h : 0, tw = ok ? (int)d.t_w : 0;
+                const int rh = ok ? (int)d.r_h : 0, rw = ok ? (int)d.r_w : 0;
+                const double *Tl = tbase + d.t_off + x, *Rl = rbase + d.r_off + x;
+                double tc[16], rc[16];
+#pragma unroll
+                for (int y = 0; y < 16; ++y) {
+                    tc[y] = (x < tw && y < th) ? Tl[y * d.t_pitch] : 0.0;
+                    rc[y] = (x < rw && y < rh) ? Rl[y * d.r_pitch] : 0.0;
+                }
+                double ts = 0.0, rs = 0.0;
+#pragma unroll
+                for (int y = 0; y < 16; ++y) {
+                    ts += tc[y];
+                    rs += rc[y];
+                }
+                const double tn = (double)(th * tw), rn = (double)(rh * rw);
+                const double tmean = row16_sum(ts) / tn, rmean = row16_sum(rs) / rn;
+                double tq = 0.0, rq = 0.0;
+#pragma unroll
+                for (int y = 0; y < 16; ++y) {
+                    tc[y] = (x < tw && y < th) ? tc[y] - tmean : 0.0;
+                    rc[y] = (x < rw && y < rh) ? rc[y] - rmean : 0.0;
+                    tq += tc[y] * tc[y];
+                    rq += rc[y] * rc[y];
+                }
+                const double tstd = sqrt(row16_sum(tq) / tn), rstd = sqrt(row16_sum(rq) / rn);
+                const bool flat = tstd < min_std;
+                if (x == 0 && s < slots) {
+                    info[s].tmean = tmean;
+                    info[s].rmean = rmean;
+                    info[s].tstd = tstd;
+                    info[s].rstd = rstd;
+                    info[s].th = th;
+                    info[s].tw = tw;
+                    info[s].rh = rh;
+                    info[s].rw = rw;
+                    info[s].state = !present ? 3 : !ok ? 2 : flat ? 1 : 0;
+                }
+                if (!ok || flat)
+                    continue;
+                float *Ts = lds + (size_t)s * slot_floats, *Ss = Ts + t_floats;
+                const int mh = min(th, rh), mw = min(tw, rw);
+                const int mwp = (mw + 3) & ~3;
+                const int gcols = (rw + G - 1) / G * G;
+                const int rcols = pair_row_cols(gcols, mwp), rxp = pair_row_pitch<G>(rcols);
+                if (x < mw) {
+#pragma unroll
+                    for (int y = 0; y < 16; ++y)
+                        if (y < mh)
+                            Ts[y * tstride + x] = (float)tc[y];
+                }
+                // S[a][x'] = (r'[a][x' mod rw], r'[(a + 1) mod rh][x' mod rw]) for x' = x, x + rw, ...
+                if (x < rw) {
+#pragma unroll
+                    for (int a = 0; a < 16; ++a) {
+                        if (a < rh) {
+                            const float cur = (float)rc[a];
+                            const float nxt = (float)((a + 1 < rh) ? rc[a + 1 < 16 ? a + 1 : 0] : rc[0]);
+                            const int sw = pair_row_swap<G>(a);
+                            for (int xx = x; xx < rcols; xx += rw)
+                                *reinterpret_cast<pf2 *>(Ss + 2 * a * rxp + ((2 * xx) ^ sw)) = pf2{cur, nxt};
+                        }
+                    }
+                }
+            }
+        } else {
         // ---- statistics and staging, one slot after the other, all lanes ----
         for (int s = 0; s < slots; ++s) {
             const int64_t p = base + s;
@@ -761,6 +877,7 @@ scan_pairs_f32_kernel(const double *__restrict__ tbase, const double *__restrict
                     cur = nxt;
                 }
             }
+        }
         }
         __syncthreads();
         PAIR_STAMP(3);          // row-pair image
@@ -996,23 +1113,25 @@ extern "C" int svamd_scan_pairs(const double *tbase, const double *rbase, const 
         const size_t lds = (size_t)slots * slot_floats * sizeof(float);
         const int64_t groups = (npairs + slots - 1) / slots;
         const unsigned fgrid = (unsigned)(groups < (1 << 20) ? groups : (1 << 20));
-        if (G == 8) {
+        const bool shared = slots > 1 && max_side <= 16;    // pairs share a wavefront: staged by rows of 16 lanes
+        auto launch = [&](auto kernel) -> int {
             if (lds > 64 * 1024) {
-                SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_pairs_f32_kernel<8>),
+                SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
             }
-            hipLaunchKernelGGL((scan_pairs_f32_kernel<8>), dim3(fgrid), dim3(fthreads), lds, st, tbase, rbase, pd, npairs,
-                               max_side, slots, tasks_per_slot, slot_floats, t_floats, s_floats, min_std, min_mean_diff,
-                               out_max, out_argmax, surfaces, surf_off);
-        } else {
-            if (lds > 64 * 1024) {
-                SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_pairs_f32_kernel<4>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-            }
-            hipLaunchKernelGGL((scan_pairs_f32_kernel<4>), dim3(fgrid), dim3(fthreads), lds, st, tbase, rbase, pd, npairs,
-                               max_side, slots, tasks_per_slot, slot_floats, t_floats, s_floats, min_std, min_mean_diff,
-                               out_max, out_argmax, surfaces, surf_off);
-        }
+            hipLaunchKernelGGL(kernel, dim3(fgrid), dim3(fthreads), lds, st, tbase, rbase, pd, npairs, max_side, slots,
+                               tasks_per_slot, slot_floats, t_floats, s_floats, min_std, min_mean_diff, out_max,
+                               out_argmax, surfaces, surf_off);
+            SV_LAUNCH_CHECK();
+            return SVAMD_OK;
+        };
+        int rc;
+        if (G == 8)
+            rc = shared ? launch(&scan_pairs_f32_kernel<8, true>) : launch(&scan_pairs_f32_kernel<8, false>);
+        else
+            rc = shared ? launch(&scan_pairs_f32_kernel<4, true>) : launch(&scan_pairs_f32_kernel<4, false>);
+        if (rc != SVAMD_OK)
+            return rc;
     } else {
         const size_t lds = elems * sizeof(double);
         // the LDS limit is per function and per device: raised before every launch that needs it
