@@ -567,6 +567,47 @@ def test_scan_pairs_shared_wavefronts_mixed_sizes(mods, oracle, max_side):
         assert_surface_close(out.cpu().numpy(), want, tol, f'pairs up to {max_side}, precision {precision}')
 
 
+def test_scan_pairs_random_boxes_f32_against_f64(mods):
+    '''Random batches of small boxes (sides 1..16, so that pairs share wavefronts and
+    are staged by rows of 16 lanes; templates larger than regions, empty templates,
+    NaN pixels, constant patches): the float32 kernel's surfaces against the
+    float64 kernel's, same NaN pattern, values within 2e-5.'''
+    import torch
+    nv = mods['n']
+    rng = np.random.default_rng(11)
+    H, W = 96, 128
+    for trial in range(24):
+        left, right = rng.random((H, W)), rng.random((H, W))
+        if trial % 3 == 0:
+            left[rng.random((H, W)) < 0.01] = np.nan
+            right[rng.random((H, W)) < 0.01] = np.nan
+        if trial % 5 == 0:
+            right[10:40, 20:70] = 0.25
+            left[50:70, 30:60] = 0.5
+        max_side = int(rng.integers(2, 17))
+        n = int(rng.integers(1, 400))
+        th = rng.integers(0 if trial % 7 == 0 else 1, max_side + 1, size=n)
+        tw, rh, rw = (rng.integers(1, max_side + 1, size=n) for _ in range(3))
+        ty, ry = (rng.integers(0, H - max_side, size=n) for _ in range(2))
+        tx, rx = (rng.integers(0, W - max_side, size=n) for _ in range(2))
+        desc = np.stack([ty * W + tx, np.full(n, W), th, tw, ry * W + rx, np.full(n, W), rh, rw], axis=1).astype(np.int64)
+        offsets = np.concatenate([[0], np.cumsum(rh * rw)]).astype(np.int64)
+        dl, dr, dd, do = nv.to_device(left), nv.to_device(right), nv.to_device(desc), nv.to_device(offsets[:-1].copy())
+        got = {}
+        for precision in (nv.ACC_F32, nv.ACC_F64):
+            out, arg = nv.empty(n, torch.float64), nv.empty(n, torch.int64)
+            surf = nv.empty(int(offsets[-1]), torch.float64)
+            nv.call('svamd_scan_pairs', nv.ptr(dl), nv.ptr(dr), nv.ptr(dd), n, max_side, 1e-4, 1e-9, precision,
+                    nv.ptr(out), nv.ptr(arg), nv.ptr(surf), nv.ptr(do), nv.stream_ptr())
+            got[precision] = (out.cpu().numpy(), surf.cpu().numpy())
+        (m32, s32), (m64, s64) = got[nv.ACC_F32], got[nv.ACC_F64]
+        assert np.array_equal(np.isnan(s32), np.isnan(s64)), f'trial {trial}: NaN pattern of the surfaces'
+        assert np.array_equal(np.isnan(m32), np.isnan(m64)), f'trial {trial}: NaN pattern of the maxima'
+        if np.isfinite(s64).any():
+            assert np.nanmax(np.abs(s32 - s64)) < 2e-5, f'trial {trial}, sides up to {max_side}'
+            assert np.nanmax(np.abs(m32 - m64)) < 2e-5
+
+
 @pytest.mark.parametrize('max_side', [12, 16])
 def test_scan_pairs_narrow_pair_after_nan_pairs(mods, max_side):
     '''A pair clipped to a few columns shares its wavefront with full-size pairs and
