@@ -168,17 +168,24 @@ fft_stats_kernel(const float *__restrict__ t, int64_t t_elems, const float *__re
     const float *tp = t + (int64_t)pair * t_elems;
     const float *rp = r + (int64_t)pair * r_elems;
     double ts = 0, tq = 0, rs = 0, rq = 0;
-    const int64_t step = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < t_elems; i += step) {
-        const double v = tp[i];
-        ts += v;
-        tq += v * v;
-    }
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < r_elems; i += step) {
-        const double v = rp[i];
-        rs += v;
-        rq += v * v;
-    }
+    const int64_t step = (int64_t)gridDim.x * blockDim.x, first = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    // eight loads in flight per thread
+    auto accumulate = [&](const float *__restrict__ p, int64_t n, double &sum, double &sq) {
+        for (int64_t base = first; base < n; base += 8 * step) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                v[k] = base + k * step < n ? p[base + k * step] : 0.0f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const double d = v[k];
+                sum += d;
+                sq += d * d;
+            }
+        }
+    };
+    accumulate(tp, t_elems, ts, tq);
+    accumulate(rp, r_elems, rs, rq);
     ts = block_sum(ts, red);
     tq = block_sum(tq, red);
     rs = block_sum(rs, red);
@@ -1006,7 +1013,7 @@ int fft_correlate(const float *tmpl, int th, int tw, const float *region, int H,
     }
     if (!raw) {
         const int64_t t_elems = (int64_t)th * tw, r_elems = (int64_t)H * W;
-        const int sblocks = (int)std::min<int64_t>(64, (r_elems + 4095) / 4096);
+        const int sblocks = (int)std::min<int64_t>(batch >= 16 ? 64 : 1024, (r_elems + 4095) / 4096);
         hipLaunchKernelGGL(fft_stats_kernel, dim3(sblocks, batch), dim3(256), 0, st, tmpl, t_elems, region,
                            r_elems, stats);
         SV_LAUNCH_CHECK();
