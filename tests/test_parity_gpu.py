@@ -568,15 +568,14 @@ def test_scan_pairs_shared_wavefronts_mixed_sizes(mods, oracle, max_side):
 
 
 def test_scan_pairs_random_boxes_f32_against_f64(mods):
-    '''Random batches of small boxes (sides 1..16, so that pairs share wavefronts and
-    are staged by rows of 16 lanes; templates larger than regions, empty templates,
-    NaN pixels, constant patches): the float32 kernel's surfaces against the
+    '''Random batches of boxes (sides 1..48: every staging mode of the float32 kernel;
+    templates larger than regions, empty templates, NaN pixels, constant patches): the float32 kernel's surfaces against the
     float64 kernel's, same NaN pattern, values within 2e-5.'''
     import torch
     nv = mods['n']
     rng = np.random.default_rng(11)
     H, W = 96, 128
-    for trial in range(24):
+    for trial in range(36):
         left, right = rng.random((H, W)), rng.random((H, W))
         if trial % 3 == 0:
             left[rng.random((H, W)) < 0.01] = np.nan
@@ -584,8 +583,9 @@ def test_scan_pairs_random_boxes_f32_against_f64(mods):
         if trial % 5 == 0:
             right[10:40, 20:70] = 0.25
             left[50:70, 30:60] = 0.5
-        max_side = int(rng.integers(2, 17))
-        n = int(rng.integers(1, 400))
+        # sides up to 16: rows of 16 lanes; 21..32: columns in registers on two wavefronts; else sweeps
+        max_side = int(rng.integers(2, 17)) if trial % 2 == 0 else int(rng.integers(17, 49))
+        n = int(rng.integers(1, 400 if max_side <= 16 else 60))
         th = rng.integers(0 if trial % 7 == 0 else 1, max_side + 1, size=n)
         tw, rh, rw = (rng.integers(1, max_side + 1, size=n) for _ in range(3))
         ty, ry = (rng.integers(0, H - max_side, size=n) for _ in range(2))
