@@ -254,7 +254,14 @@ fft_cols_fused_kernel(float2 *__restrict__ spec_t, const float2 *__restrict__ sp
     const int S = 2 * cols;
     float2 *tile = lds;                     // [H][S]
     float2 *twl = lds + H * S;              // [H]
-    const int c0 = blockIdx.x * cols, pair = blockIdx.y;
+    // Workgroups go to the 8 XCDs in turn, and a tile is a fraction of a 128-byte line in every
+    // row: consecutive tiles are given to workgroups of ONE XCD (block b -> tile (b % 8) * n/8 +
+    // b / 8, the grid is a multiple of 8 wide), so that the neighbours that share lines share an L2.
+    const int per_xcd = gridDim.x / 8;
+    const int tile_index = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+    const int c0 = tile_index * cols, pair = blockIdx.y;
+    if (c0 >= ncols)
+        return;
     float2 *gt = spec_t + (int64_t)pair * H * hp;
     const float2 *gr = spec_r + (int64_t)pair * H * hp;
     for (int i = threadIdx.x; i < H * cols; i += blockDim.x) {
@@ -1026,7 +1033,7 @@ int fft_correlate(const float *tmpl, int th, int tw, const float *region, int H,
     const int cols = H <= 1024 ? FFT_COLS : H == 2048 ? 4 : 2;
     const size_t lds = ((size_t)H * 2 * cols + H) * sizeof(float2);
     SV_HIP(allow_lds(&fft_cols_fused_kernel, lds));
-    hipLaunchKernelGGL(fft_cols_fused_kernel, dim3((ncols + cols - 1) / cols, batch), dim3(FFT_COL_THREADS), lds,
+    hipLaunchKernelGGL(fft_cols_fused_kernel, dim3(((ncols + cols - 1) / cols + 7) / 8 * 8, batch), dim3(FFT_COL_THREADS), lds,
                        st, spec_t, spec_r, H, log2h, ncols, hp, cols, tw_h);
     SV_LAUNCH_CHECK();
     dim3 g3((H + 1) / 2, batch);
