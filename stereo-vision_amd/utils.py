@@ -13,7 +13,8 @@ import _native as nv
 class ResidentImage(np.ndarray):
     '''A host image that remembers its float64 twin in GPU memory (`resident`),
     so that the scans need not upload it again.  It is read-only: edit a copy
-    (`np.array(image)`), which is an ordinary array without a twin.  Slices and
+    (`np.array(image)`), which is an ordinary array without a twin, or call
+    `image.setflags(write=True)`, which drops the twin.  Slices and
     results of arithmetic are ordinary in that sense too.'''
 
     def __new__(cls, host, resident):
@@ -24,6 +25,13 @@ class ResidentImage(np.ndarray):
 
     def __array_finalize__(self, obj):
         self.resident = None
+
+    def setflags(self, write=None, align=None, uic=None):
+        '''Making the image writable (`image.setflags(write=True)`) gives up the
+        device twin first: an edited host image must be uploaded again.'''
+        if write:
+            self.resident = None
+        super().setflags(write=write, align=align, uic=uic)
 
 
 def resident_float64(image):

@@ -104,6 +104,11 @@ def test_resident_image_is_a_read_only_array_with_a_twin():
     editable[0, 0] = 5.0
     assert type(editable) is np.ndarray and host[0, 0] == 0.0
     assert np.array_equal(np.asarray(image), host) and float(image.sum()) == 66.0
+    # making it writable gives up the twin first
+    image.setflags(write=True)
+    assert image.resident is None
+    image[0, 0] = 5.0
+    assert image[0, 0] == 5.0
 
 
 def test_band_scan_input_levels():
@@ -135,3 +140,4 @@ def test_dot_grouping_matches_scipy_labelling():
     assert sc.group_boxes(np.array([], dtype=int), np.array([], dtype=int)) == []
     xg, yg = np.meshgrid(np.linspace(-5, 5, 101), np.linspace(-5, 5, 101))
     assert np.array_equal(np.exp(-(np.power(xg, 2) + np.power(yg, 2))), sc.dot_template())
+
