@@ -36,12 +36,15 @@ int stats_launch(const void *src, int dtype, int h, int w, int64_t pitch, bool i
 // slide_partial_doubles() doubles; with sx > 1 `partial_cap` doubles, which
 // bounds how many ways the strided kernel may split the template columns
 // (slide_strided_partial_doubles() is the customary amount; 0 = no split).
+// `planes_left`: when given, partial planes are not added up: their number is
+// returned (1: the sums are in `out`; more: plane z is partial + z * oh * ow) and
+// the caller's next kernel adds them.
 size_t slide_pack_floats(int th, int tw);
 size_t slide_partial_doubles(int tw, int64_t oh, int64_t ow);
 size_t slide_strided_partial_doubles(int64_t rh, int64_t rw);
 int slide_launch(const float *t, int th, int tw, const float *img, int64_t img_pitch, int eh, int ew,
                  int oh, int ow, int sx, int sy, double *out, float *pack, double *partial,
-                 hipStream_t stream, size_t partial_cap = 0);
+                 hipStream_t stream, size_t partial_cap = 0, int *planes_left = nullptr);
 
 // fft_xcorr.hip
 // Plain circular correlation of two P x Q float32 arrays (P, Q powers of two within

@@ -188,6 +188,7 @@ int sat2d_launch(const TIn *img, int h, int w, int64_t pitch, TAcc offset, TAcc 
     int64_t blocks = (65536 + 2 * tp - 1) / (2 * tp);
     if (blocks > 32) blocks = 32;
     if (blocks > h / 8) blocks = h / 8;
+    if (h < 256) blocks = 1;           // short tables: two launches cost more than the chain they shorten
     const int64_t room = scratch ? (int64_t)(scratch_bytes / (2 * tp * sizeof(TAcc))) : 0;
     if (blocks > room) blocks = room;
     if (blocks >= 2) {

@@ -163,20 +163,6 @@ __device__ __forceinline__ double centre_value(const Stats *st, int dtype)
     return dtype == SVAMD_U8 ? rint(st->mean) : st->mean;
 }
 
-// The mean of an array from the last entry of its summed-area table (exact for
-// integer tables).  Only `mean` and `count` are filled in.
-template <typename TSat>
-__global__ void mean_from_sat_kernel(const TSat *__restrict__ s1, int h, int w, Stats *__restrict__ out)
-{
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        const double n = (double)h * (double)w;
-        out->mean = (double)s1[(int64_t)h * (w + 1) + w] / n;
-        out->std = 0.0;
-        out->count = n;
-        out->pad = 0.0;
-    }
-}
-
 // ---- operand preparation ----------------------------------------------------------
 // Mean-removed template in float32 (masked pixels -> 0).
 __global__ void __launch_bounds__(256)
@@ -198,9 +184,12 @@ prep_template_kernel(const void *__restrict__ t, int dtype, int th, int tw, int6
 __global__ void __launch_bounds__(256)
 extend_kernel(const void *__restrict__ src, int dtype, int rh, int rw, int64_t pitch, int mode,
               int exact_mean, const Stats *__restrict__ st, int eh, int ew, int64_t epitch,
-              float *__restrict__ ext)
+              float *__restrict__ ext, const int64_t *__restrict__ table_total)
 {
-    const double c = exact_mean ? st->mean : centre_value(st, dtype);
+    // table_total (uint8 regions): the last entry of the region's exact integer table of
+    // sums; the rounded mean taken from it needs neither `st` nor a pass over the region
+    const double c = table_total ? rint((double)*table_total / ((double)rh * (double)rw))
+                                 : exact_mean ? st->mean : centre_value(st, dtype);
     const int64_t total = (int64_t)eh * epitch;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
          i += (int64_t)gridDim.x * blockDim.x) {
@@ -820,7 +809,7 @@ static int strided_piece_groups(int K, int tw)
 
 static int slide_strided_launch(const float *t, int th, int tw, const float *img, int64_t img_pitch, int eh,
                                 int ew, int oh, int ow, int sx, int sy, double *out, float *pack,
-                                double *partial, size_t partial_cap, hipStream_t stream)
+                                double *partial, size_t partial_cap, hipStream_t stream, int *planes_left)
 {
     StridedGeom g;
     g.th = th; g.tw = tw; g.oh = oh; g.ow = ow; g.sx = sx; g.sy = sy; g.eh = eh; g.ew = ew;
@@ -861,7 +850,9 @@ static int slide_strided_launch(const float *t, int th, int tw, const float *img
     default: strided_dispatch<1>(n4, grid, lds, stream, g, pack, img, dst); break;
     }
     SV_LAUNCH_CHECK();
-    if (nz > 1) {
+    if (planes_left) {
+        *planes_left = (int)nz;                    // the caller adds the planes up itself
+    } else if (nz > 1) {
         hipLaunchKernelGGL(slide_reduce_kernel, dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, stream,
                            partial, nz, plane, out);
         SV_LAUNCH_CHECK();
@@ -872,11 +863,11 @@ static int slide_strided_launch(const float *t, int th, int tw, const float *img
 // `partial_cap`: doubles available behind `partial` (only the strided kernel asks).
 int slide_launch(const float *t, int th, int tw, const float *img, int64_t img_pitch, int eh, int ew,
                  int oh, int ow, int sx, int sy, double *out, float *pack, double *partial,
-                 hipStream_t stream, size_t partial_cap)
+                 hipStream_t stream, size_t partial_cap, int *planes_left)
 {
     if (sx != 1)
         return slide_strided_launch(t, th, tw, img, img_pitch, eh, ew, oh, ow, sx, sy, out, pack, partial,
-                                    partial_cap, stream);
+                                    partial_cap, stream, planes_left);
     SlideGeom g;
     g.th = th; g.tw = tw; g.lp = slide_lp(tw);
     g.oh = oh; g.ow = ow; g.sy = sy; g.eh = eh; g.ew = ew; g.pitch = img_pitch;
@@ -927,7 +918,9 @@ int slide_launch(const float *t, int th, int tw, const float *img, int64_t img_p
         hipLaunchKernelGGL(slide_tiled_kernel<ST_STAGE_Q>, grid, dim3(g.waves * WAVE), lds, stream, g, pack, img,
                            nz > 1 ? partial : out);
     SV_LAUNCH_CHECK();
-    if (nz > 1) {
+    if (planes_left) {
+        *planes_left = nz;
+    } else if (nz > 1) {
         const int64_t total = (int64_t)oh * ow;
         hipLaunchKernelGGL(slide_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
                            partial, nz, total, out);
@@ -953,12 +946,22 @@ __global__ void __launch_bounds__(256)
 spatial_epilogue_kernel(double *__restrict__ out, int orows, int ocols, int sx, int sy, int th, int tw,
                         int rh, int rw, int region_dtype, const Stats *__restrict__ tst,
                         const Stats *__restrict__ rst, const double *__restrict__ tsat,
-                        const TSat *__restrict__ s1, const TSat *__restrict__ s2)
+                        const TSat *__restrict__ s1, const TSat *__restrict__ s2,
+                        const double *__restrict__ planes, int nplanes)
 {
     const int64_t total = (int64_t)orows * ocols;
     const int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (idx >= total)
         return;
+    // the sliding kernel's sums: in `out`, or still spread over `nplanes` partial planes
+    double raw;
+    if (nplanes > 1) {
+        raw = 0.0;
+        for (int z = 0; z < nplanes; ++z)
+            raw += planes[(int64_t)z * total + idx];
+    } else {
+        raw = out[idx];
+    }
     const int i = (int)(idx / ocols), j = (int)(idx - (int64_t)i * ocols);
     const int y0 = i * sy, x0 = j * sx;
     const int h = min(th, rh - y0), w = min(tw, rw - x0);
@@ -992,9 +995,11 @@ spatial_epilogue_kernel(double *__restrict__ out, int orows, int ocols, int sx, 
         rstd = sqrt(var);
     }
     const double tstd = tst->std;
-    const double shift = std::is_integral<TSat>::value ? centre_value(rst, region_dtype) - rmean : -rmean;
+    double shift = -rmean;
+    if constexpr (std::is_integral<TSat>::value)      // pixels were centred by the rounded region mean
+        shift = rint((double)s1[(int64_t)rh * tp + rw] / ((double)rh * (double)rw)) - rmean;
     const double tcrop = tsat[(int64_t)h * (tw + 1) + w];
-    double v = (out[idx] + shift * tcrop) / ((double)th * (double)tw);
+    double v = (raw + shift * tcrop) / ((double)th * (double)tw);
     if (tstd == 0.0 || flat)
         v = NAN;
     else
@@ -1168,10 +1173,7 @@ extern "C" int svamd_cross_correlate_2d(const double *tmpl, int th, int tw, cons
         if ((rc = sat2d_any(region, region_dtype, rh, rw, rw, 0.0, s1, s2, st, ext, ext_bytes)) != SVAMD_OK) return rc;
         // The region's mean only serves as the constant the pixels are centred by before
         // they are rounded to float32 (the epilogue puts the window's own mean back): the
-        // exact integer table's last entry gives it without another pass over the region.
-        hipLaunchKernelGGL((mean_from_sat_kernel<int64_t>), dim3(1), dim3(64), 0, st,
-                           static_cast<const int64_t *>(s1), rh, rw, rst);
-        SV_LAUNCH_CHECK();
+        // kernels that need it read the exact integer table's last entry.
     } else {
         // Floating pixels: float64 tables of (pixel - region mean).  Tables of the plain
         // pixels lose a window's variance in the rounding of sums of squares as soon as
@@ -1182,21 +1184,24 @@ extern "C" int svamd_cross_correlate_2d(const double *tmpl, int th, int tw, cons
             return rc;
     }
     hipLaunchKernelGGL(extend_kernel, dim3(grid_for((int64_t)L.n_ext)), dim3(256), 0, st, region,
-                       region_dtype, rh, rw, (int64_t)rw, 0, 0, rst, L.eh, L.ew, L.epitch, ext);
+                       region_dtype, rh, rw, (int64_t)rw, 0, 0, rst, L.eh, L.ew, L.epitch, ext,
+                       region_dtype == SVAMD_U8 ? static_cast<const int64_t *>(s1) + (int64_t)rh * (rw + 1) + rw
+                                                : nullptr);
     SV_LAUNCH_CHECK();
+    int nplanes = 1;     // the epilogue adds the sliding kernel's partial planes up itself
     if ((rc = slide_launch(tp, th, tw, ext, L.epitch, L.eh, L.ew, orows, ocols, step_x, step_y, out, pack,
-                           partial, st, partial_cap)) != SVAMD_OK)
+                           partial, st, partial_cap, &nplanes)) != SVAMD_OK)
         return rc;
     const int64_t total = (int64_t)orows * ocols;
     dim3 eg((unsigned)((total + 255) / 256));
     if (region_dtype == SVAMD_U8)
         hipLaunchKernelGGL((spatial_epilogue_kernel<int64_t>), eg, dim3(256), 0, st, out, orows, ocols,
                            step_x, step_y, th, tw, rh, rw, region_dtype, tst, rst, tsat,
-                           static_cast<const int64_t *>(s1), static_cast<const int64_t *>(s2));
+                           static_cast<const int64_t *>(s1), static_cast<const int64_t *>(s2), partial, nplanes);
     else
         hipLaunchKernelGGL((spatial_epilogue_kernel<double>), eg, dim3(256), 0, st, out, orows, ocols,
                            step_x, step_y, th, tw, rh, rw, region_dtype, tst, rst, tsat,
-                           static_cast<const double *>(s1), static_cast<const double *>(s2));
+                           static_cast<const double *>(s1), static_cast<const double *>(s2), partial, nplanes);
     SV_LAUNCH_CHECK();
     return SVAMD_OK;
 }
@@ -1313,7 +1318,7 @@ extern "C" int svamd_cross_correlate_2d_spectral(const void *tmpl, int tmpl_dtyp
     SV_LAUNCH_CHECK();
     // region minus its exact mean, wrapped circularly
     hipLaunchKernelGGL(extend_kernel, dim3(grid_for((int64_t)eh * epitch)), dim3(256), 0, st, region,
-                       region_dtype, rh, rw, (int64_t)rw, 1, 1, rst, eh, ew, epitch, ext);
+                       region_dtype, rh, rw, (int64_t)rw, 1, 1, rst, eh, ew, epitch, ext, nullptr);
     SV_LAUNCH_CHECK();
     if ((rc = slide_launch(tp, mh, mw, ext, epitch, eh, ew, rh, rw, 1, 1, out, pack, partial, st)) != SVAMD_OK)
         return rc;
