@@ -201,7 +201,7 @@ fft_stats_kernel(const float *__restrict__ t, int64_t t_elems, const float *__re
 // ---- pass 1: packed row transform ---------------------------------------------------
 // One workgroup per (row, pair).  spec_t / spec_r: [pair][H][hp] complex, hp = W/2 + 16.
 // raw != 0: the arrays are transformed as they are (no mean removed).
-__global__ void __launch_bounds__(FFT_THREADS)
+__global__ void __launch_bounds__(1024)
 fft_rows_forward_kernel(const float *__restrict__ t, int th, int tw_, const float *__restrict__ r, int H,
                         int W, int log2w, const FftStats *__restrict__ stats,
                         const float2 *__restrict__ twiddle, float2 *__restrict__ spec_t,
@@ -291,7 +291,7 @@ fft_cols_fused_kernel(float2 *__restrict__ spec_t, const float2 *__restrict__ sp
 // ---- pass 3: inverse row transform of two rows at a time, scaling ---------------------
 // raw != 0: the plain circular correlation sum (scaled by 1 / (H W) only).
 template <typename TOut>
-__global__ void __launch_bounds__(FFT_THREADS)
+__global__ void __launch_bounds__(1024)
 fft_rows_inverse_kernel(const float2 *__restrict__ spec, int th, int tw_, int H, int W, int log2w, int hp,
                         const FftStats *__restrict__ stats, double min_std, double min_mean_diff,
                         const float2 *__restrict__ twiddle, TOut *__restrict__ out, int raw)
@@ -1026,8 +1026,10 @@ int fft_correlate(const float *tmpl, int th, int tw, const float *region, int H,
         SV_LAUNCH_CHECK();
     }
     const size_t row_lds = (size_t)2 * W * sizeof(float2);
+    // 4096-point rows: two workgroups fit a CU's LDS, so they had better be large
+    const int row_threads = W >= 4096 ? 1024 : FFT_THREADS;
     SV_HIP(allow_lds(&fft_rows_forward_kernel, row_lds));
-    hipLaunchKernelGGL(fft_rows_forward_kernel, dim3(H, batch), dim3(FFT_THREADS), row_lds, st, tmpl, th, tw,
+    hipLaunchKernelGGL(fft_rows_forward_kernel, dim3(H, batch), dim3(row_threads), row_lds, st, tmpl, th, tw,
                        region, H, W, log2w, stats, tw_w, spec_t, spec_r, hp, raw);
     SV_LAUNCH_CHECK();
     const int cols = H <= 1024 ? FFT_COLS : H == 2048 ? 4 : 2;
@@ -1039,11 +1041,11 @@ int fft_correlate(const float *tmpl, int th, int tw, const float *region, int H,
     dim3 g3((H + 1) / 2, batch);
     if (out_dtype == SVAMD_F32) {
         SV_HIP(allow_lds(&fft_rows_inverse_kernel<float>, row_lds));
-        hipLaunchKernelGGL((fft_rows_inverse_kernel<float>), g3, dim3(FFT_THREADS), row_lds, st, spec_t, th, tw, H,
+        hipLaunchKernelGGL((fft_rows_inverse_kernel<float>), g3, dim3(row_threads), row_lds, st, spec_t, th, tw, H,
                            W, log2w, hp, stats, min_std, min_mean_diff, tw_w, static_cast<float *>(out), raw);
     } else {
         SV_HIP(allow_lds(&fft_rows_inverse_kernel<double>, row_lds));
-        hipLaunchKernelGGL((fft_rows_inverse_kernel<double>), g3, dim3(FFT_THREADS), row_lds, st, spec_t, th, tw, H,
+        hipLaunchKernelGGL((fft_rows_inverse_kernel<double>), g3, dim3(row_threads), row_lds, st, spec_t, th, tw, H,
                            W, log2w, hp, stats, min_std, min_mean_diff, tw_w, static_cast<double *>(out), raw);
     }
     SV_LAUNCH_CHECK();
