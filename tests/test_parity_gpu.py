@@ -153,6 +153,33 @@ def test_spatial_float_region_with_large_mean(mods, oracle):
     assert np.unravel_index(np.argmax(got), got.shape) == (20, 20)
 
 
+def test_spatial_random_shapes_and_steps_vs_oracle(mods, oracle):
+    '''Random template / region shapes (1 x 1 up to 300 x 700) and steps 1..8 in each
+    direction, uint8 regions with and without a NaN-masked template and float regions:
+    every launch geometry of the table, sliding (unit and strided columns, row and
+    column slices) and epilogue kernels against the oracle.'''
+    rng = np.random.default_rng(5)
+    for trial in range(60):
+        rh, rw = int(rng.integers(1, 300)), int(rng.integers(1, 700))
+        th, tw = int(rng.integers(1, rh + 1)), int(rng.integers(1, rw + 1))
+        if trial % 4 == 0:
+            th, tw = min(th, 40), min(tw, 40)
+        sx, sy = int(rng.integers(1, 9)), int(rng.integers(1, 9))
+        if trial % 3 == 0:
+            sx = 1
+        if trial % 5 == 0:
+            sy = 1
+        kind = trial % 3
+        region = (rng.integers(0, 256, size=(rh, rw), dtype=np.uint8) if kind != 2
+                  else rng.random((rh, rw)) * 3 + 10)
+        template = rng.random((th, tw)) * 255
+        if kind == 1 and th * tw > 4:
+            template[rng.random((th, tw)) < 0.15] = np.nan
+        got = quiet(mods['c'].cross_correlate_2d, template, region, sx, sy)
+        want = oracle.cross_correlate_2d(template, region.astype(np.float64), sx, sy)
+        assert_surface_close(got, want, 2e-5, f'trial {trial}: {(th, tw)} over {(rh, rw)}, steps {(sx, sy)}, kind {kind}')
+
+
 def test_spatial_template_exceeds_region(mods):
     with pytest.raises(Exception, match='Dimensions of template must not exceed those of region.'):
         mods['c'].cross_correlate_2d(np.zeros((5, 5)), np.zeros((4, 9), np.uint8))
