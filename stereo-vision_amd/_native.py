@@ -82,6 +82,16 @@ def load_library():
             raise RuntimeError(
                 f'{LIB_PATH} is missing: build it with `make -C {_HERE}` '
                 '(hipcc --offload-arch=gfx950); there is no CPU fallback')
+        # libsvamd.so brings the system's HIP runtime along, PyTorch-ROCm its own copy; both
+        # live in the process.  The one PyTorch uses has to be initialised first: with the
+        # library (and the system runtime) loaded before PyTorch has touched the GPU, the
+        # library's first kernel launch fails with "no ROCm-capable device is detected".
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except ImportError:
+            pass
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(lib, name)

@@ -186,6 +186,33 @@ def test_spatial_template_exceeds_region(mods):
 
 
 # ---- a2 ------------------------------------------------------------------------
+def test_spectral_random_shapes_vs_oracle(mods, oracle):
+    '''Random template / region shapes through cross_correlate_2d_spectral (templates up to
+    twice the region: zero-padded, cropped, both), with constant templates (the
+    low-deviation branch), constant regions (NaN surface; constants that are exact in
+    binary, as the reference's 0/0 depends on it) and uint8 regions: pair kernel and
+    sliding route against the oracle's direct circular correlation.'''
+    rng = np.random.default_rng(8)
+    for trial in range(60):
+        big = trial % 3 == 0
+        rh, rw = ((int(rng.integers(1, 130)), int(rng.integers(1, 130))) if big
+                  else (int(rng.integers(1, 65)), int(rng.integers(1, 65))))
+        th, tw = int(rng.integers(1, 2 * rh + 1)), int(rng.integers(1, 2 * rw + 1))
+        if not big:
+            th, tw = min(th, 64), min(tw, 64)
+        t, r = rng.random((th, tw)), rng.random((rh, rw))
+        if trial % 7 == 0:
+            t[:] = 0.25
+        if trial % 11 == 0:
+            r[:] = 0.5
+        if trial % 13 == 0:
+            r = (r * 255).astype(np.uint8)
+        got = mods['s'].cross_correlate_2d_spectral(t, r)
+        with np.errstate(all='ignore'):
+            want = oracle.cross_correlate_2d_spectral(t, np.asarray(r, dtype=np.float64))
+        assert_surface_close(got, want, 2e-5, f'trial {trial}: {(th, tw)} against {(rh, rw)}')
+
+
 def test_g4_spectral_small(mods):
     g = golden('g4_spectral_small')
     tags = sorted(k[:-4] for k in g.files if k.endswith('_out'))
