@@ -93,6 +93,13 @@ def cross_correlate_2d_spectral(orig_template: np.ndarray, orig_region: np.ndarr
     region = np.asarray(orig_region)
     th, tw = template.shape
     rh, rw = region.shape
+    if template.size == 0 and region.size > 0:
+        # An empty template (a box cut off at the image edge) has nothing to transform:
+        # the reference's zero-padded transform of it is all zeros, so the surface is 0
+        # wherever the normalised region is finite - and NaN everywhere for a constant
+        # region, whose normalisation is 0 / 0 (correlation_spectral.py:37-54).
+        flat = float(np.std(region)) == 0.0 or bool(np.isnan(region).any())
+        return np.full(region.shape, np.nan if flat else 0.0)
     if max(th, tw, rh, rw) <= nv.PAIR_MAX_SIDE and min(th, tw, rh, rw) > 0:
         return _small_pair_surface(template, region)
     overlap = min(th, rh) * min(tw, rw)

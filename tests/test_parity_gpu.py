@@ -442,6 +442,56 @@ def test_sat2d_tables(mods):
 
 
 # ---- scans ---------------------------------------------------------------------
+def test_spectral_empty_template(mods):
+    '''A template box cut off to nothing at the image edge: the reference's zero-padded
+    transform of it is zero, so the surface is 0 - NaN for a constant region (0 / 0).'''
+    r = np.random.default_rng(0).random((6, 7))
+    for t in (np.zeros((0, 4)), np.zeros((3, 0))):
+        assert np.array_equal(mods['s'].cross_correlate_2d_spectral(t, r), np.zeros((6, 7)))
+        assert np.isnan(mods['s'].cross_correlate_2d_spectral(t, np.full((6, 7), 0.5))).all()
+
+
+def test_sequence_scan_random_configs_vs_oracle(mods, oracle):
+    '''Random small stereo pairs (shifted, noisy, some with a homogeneous patch) under
+    random configs - window 5..25, schemes up to 9 x 5, shifts 0..2, four overlaps, three
+    thresholds, one or two multi-pass stages of factor 2 or 3: every window's dp, centre,
+    stage centres and stage sizes against the oracle's window-by-window scan.'''
+    v = mods['v']
+    rng = np.random.default_rng(21)
+    for trial in range(20):
+        H, W = int(rng.integers(40, 130)), int(rng.integers(40, 150))
+        base = rng.integers(0, 256, size=(H + 20, W + 20)).astype(np.float64)
+        base = (base + np.roll(base, 1, 0) + np.roll(base, 1, 1) + np.roll(base, (1, 1), (0, 1))) / 4
+        dx, dy = int(rng.integers(-4, 5)), int(rng.integers(-2, 3))
+        left = np.round(base[10:10 + H, 10:10 + W]) / 255.0
+        right = np.round(base[10 - dy:10 - dy + H, 10 - dx:10 - dx + W] + rng.normal(0, 2, (H, W))).clip(0, 255) / 255.0
+        if trial % 6 == 0:
+            left[5:25, 5:30] = 0.5
+            right[5:25, 5:30] = 0.5
+        w, h = int(rng.integers(5, 26)), int(rng.integers(5, 26))
+        cfg = [dict(window_width=w, window_height=h,
+                    scheme=[int(rng.choice([1, 3, 5, 7, 9])), int(rng.choice([1, 3, 5]))],
+                    scheme_shift_size=[int(rng.integers(0, 3)), int(rng.integers(0, 3))],
+                    window_overlap=float(rng.choice([0.0, 0.25, 0.5, 0.6])),
+                    correlation_threshold=float(rng.choice([0.0, 0.3, 0.8])))]
+        if trial % 2 == 0 and min(w, h) >= 8:
+            cfg.append(dict(factor=int(rng.choice([2, 3]))))
+            if trial % 4 == 0 and min(w, h) >= 16:
+                cfg.append(dict(factor=2))
+        got = quiet(v.sequence_scan, left, right, cfg)
+        want = oracle.sequence_scan(left, right, cfg)
+        assert len(got) == len(want)
+        for stage, stage_want in enumerate(want):
+            assert set(got[stage]) == set(stage_want), f'trial {trial} stage {stage}: window ids'
+            for wid, ww in stage_want.items():
+                g = got[stage][wid]
+                what = f'trial {trial} {cfg} stage {stage} window {wid}'
+                assert (g['dp_x'], g['dp_y']) == (ww['dp_x'], ww['dp_y']), what
+                assert tuple(g['centre']) == tuple(ww['centre']), what
+                assert [tuple(c) for c in g['stage_centres']] == [tuple(c) for c in ww['stage_centres']], what
+                assert [tuple(c) for c in g['stage_sizes']] == [tuple(c) for c in ww['stage_sizes']], what
+
+
 def check_scan(mods, g, left, right, precisions=('mixed',)):
     v = mods['v']
     cfg = json.loads(str(g['config']))
