@@ -441,6 +441,39 @@ def test_sat2d_tables(mods):
         nv.call('svamd_sat2d', nv.ptr(d), nv.U8, 4, 4, 4, 0.5, nv.ptr(s1), nv.ptr(s2), nv.stream_ptr())
 
 
+def test_band_scan_random_geometries_vs_oracle(mods, oracle):
+    '''Random window widths (unrolled and run-time instantiations), heights, image sizes,
+    offset ranges, row strides and both selection modes of the dense band scan against
+    the oracle: disparities and NaN patterns exactly, scores to 1e-11.'''
+    import band_scan as bs
+    rng = np.random.default_rng(31)
+    for trial in range(30):
+        ww = int(rng.choice([3, 5, 7, 8, 11, 12, 15, 16, 21, 25, 30, 31, 33, 40]))
+        wh = int(rng.integers(1, min(40, 1024 // ww) + 1))
+        H, W = wh + int(rng.integers(0, 90)), ww + int(rng.integers(0, 400))
+        md = int(rng.integers(0, 70))
+        stride = int(rng.choice([1, 1, 2, 3, 5]))
+        left = rng.integers(0, 256, size=(H, W), dtype=np.uint8)
+        shift = int(rng.integers(-min(md, 20), min(md, 20) + 1)) if md else 0
+        right = np.clip(np.roll(left, shift, axis=1).astype(int) + rng.integers(-3, 4, size=(H, W)), 0, 255).astype(np.uint8)
+        if trial % 5 == 0:
+            left[: H // 2, : W // 3] = 77
+            right[: H // 2, : W // 3] = 77
+        thr = None if trial % 2 else float(rng.choice([0.0, 0.5, 0.9]))
+        disp, val, scores = bs.band_scan(left, right, ww, wh, md, correlation_threshold=thr, row_stride=stride,
+                                         want_scores=True)
+        od, ov, osc = oracle.band_scan(left, right, ww, wh, md, stride_y=stride,
+                                       mode='argmax' if thr is None else 'fold',
+                                       threshold=0.0 if thr is None else thr, want_scores=True)
+        what = f'trial {trial}: window {(ww, wh)} image {(H, W)} offsets {md} stride {stride} threshold {thr}'
+        assert disp.shape == od.shape and np.array_equal(disp, od), what
+        assert np.array_equal(np.isnan(scores), np.isnan(osc)) and np.array_equal(np.isnan(val), np.isnan(ov)), what
+        if np.isfinite(osc).any():
+            assert np.nanmax(np.abs(scores - osc)) <= 1e-11, what
+        if np.isfinite(ov).any():
+            assert np.nanmax(np.abs(val - ov)) <= 1e-11, what
+
+
 # ---- scans ---------------------------------------------------------------------
 def test_spectral_empty_template(mods):
     '''A template box cut off to nothing at the image edge: the reference's zero-padded
