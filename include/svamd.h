@@ -44,6 +44,9 @@ extern "C" {
 /* precision of the multiply-accumulate in svamd_scan_pairs */
 #define SVAMD_ACC_F32 0
 #define SVAMD_ACC_F64 1
+/* svamd_scan_grid only: float32, then float64 for every window whose selection came
+ * within the guard band of flipping, and for the value each window reports */
+#define SVAMD_ACC_MIXED 2
 
 /* selection rule of svamd_band_scan_u8 */
 #define SVAMD_BAND_ARGMAX 0     /* first maximum in ascending offset (utils.py:17-26) */
@@ -172,6 +175,46 @@ int svamd_scan_pairs(const double *tbase, const double *rbase,
 int svamd_scan_fold(const double *corr_max, const uint8_t *is_centre, const uint8_t *skip,
                     const int64_t *win_off, int64_t nwin, double threshold, double centre_tol,
                     int64_t *best_pair, double *best_val, double *min_margin, void *stream);
+
+/* ---- a7 stage 0 + a8: whole_image_search_regions / region_pairs + image_scan per window
+ * sv_image_comparison.py:35-47,74-79 with :143-191, :119-141, :283-298 and :229-255,
+ * for window rows [row_begin, row_end) of the first stage, without a host-side list
+ * of pairs.  The windows tile the left image on an nrow x ncol grid; a window's
+ * candidate regions are slot 0 = its own position, then slot 1 + iy * nx + ix = the
+ * scheme grid row by row (region_pairs' order), each the cross product of a per-column
+ * and a per-row candidate.  The caller supplies per-axis tables (int32, device):
+ *   xcand [ncol][1 + nx][SVAMD_GRID_CAND_FIELDS] = {begin, end, flags, rank, centre_rank}
+ *     begin/end: the candidate's clipped box along the axis (get_window_boundaries,
+ *     :294-297); flags: 1 = rejected by :288-292, 2 = equals the window's own centre
+ *     (region_pairs drops that grid candidate, :136-140); rank / centre_rank: how many
+ *     grid candidates before this one in its column are not rejected / are not
+ *     rejected and at the centre.  Entry 0 is the window's own position.
+ *   xwin [ncol][SVAMD_GRID_XWIN_FIELDS] = {t_begin, t_end, own_ok, valid, centred,
+ *     own_before, valid_before, centred_before}: the template's extent along the axis
+ *     (:170), whether the own position survives, the number of surviving grid
+ *     candidates, how many of them sit at the centre, and the sums of those three over
+ *     the columns to the left.
+ *   ycand [nrow][1 + ny][...] likewise; ywin [nrow][SVAMD_GRID_YWIN_FIELDS] = the first
+ *     five fields.
+ *   row_first [nrow + 1] int64: index of each window row's first pair in the whole
+ *     stage (a window (r, c) has own_ok + valid_y * valid_x - centred_y * centred_x pairs).
+ * npairs = row_first[row_end] - row_first[row_begin] sizes the workspace (at most 2^31 - 1
+ * per call: scan fewer rows at a time).  left / right: float64 images with row pitches in
+ * elements.  precision: SVAMD_ACC_F32, SVAMD_ACC_F64 or SVAMD_ACC_MIXED.
+ * best_slot / best_val: nrow * ncol entries indexed by window id (row-major); the call
+ * writes rows [row_begin, row_end): the selected candidate slot or -1, and its
+ * correlation or 0 (image_scan's return value, :281). */
+#define SVAMD_GRID_CAND_FIELDS 5
+#define SVAMD_GRID_XWIN_FIELDS 8
+#define SVAMD_GRID_YWIN_FIELDS 5
+size_t svamd_scan_grid_workspace_bytes(int64_t nwin, int64_t npairs);
+int svamd_scan_grid(const double *left, int64_t left_pitch, const double *right, int64_t right_pitch,
+                    const int32_t *xcand, const int32_t *xwin, int ncol, int nx,
+                    const int32_t *ycand, const int32_t *ywin, int nrow, int ny,
+                    const int64_t *row_first, int row_begin, int row_end, int64_t npairs,
+                    int max_side, double min_std, double min_mean_diff, double threshold,
+                    double centre_tol, int precision, double guard_band, int32_t *best_slot,
+                    double *best_val, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- dense band scan ------------------------------------------------------------
  * For every win_w x win_h window of the left image (origins on a stride grid,

@@ -160,10 +160,11 @@ def config3():
     emit(config=3, what='sequence_scan portal config, synthetic 960x1080', seconds=dt, windows=nwin,
          pairs=pairs, nonzero=moved, pairs_per_s=pairs / dt, surface_elems_per_s=pairs * 144 / dt)
     # device-only time of the pair kernel for the cone scan
-    windows, stage_boxes = sv_image_comparison._stage0_windows(left, right, 12, 12, (11, 1), (1, 0), 0)
-    batch = sv_image_comparison._StageBatch(left.shape[1], right.shape[1])
-    batch.add_arrays(*stage_boxes[:4])
-    desc = nv.to_device(batch.desc())
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from helpers import enumerate_grid_pairs
+    grid = sv_image_comparison._Stage0Grid(left, right, 12, 12, (11, 1), (1, 0), 0)
+    desc = nv.to_device(enumerate_grid_pairs(grid.tables(), grid.ncol, 11, grid.nrow, 1, 0, grid.nrow,
+                                             left.shape[1], right.shape[1])[0])
     dl, dr = nv.to_device(left), nv.to_device(right)
     out = nv.empty(desc.shape[0], torch.float64)
     for precision, tag in ((nv.ACC_F32, 'f32'), (nv.ACC_F64, 'f64')):

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get('SVAMD_LIBRARY') or os.path.join(_HERE, 'libsvamd.so')
 
 OK, ERR_INVALID, ERR_SHAPE, ERR_WORKSPACE, ERR_HIP, ERR_LIMIT = range(6)
 U8, F32, F64 = 0, 1, 2
-ACC_F32, ACC_F64 = 0, 1
+ACC_F32, ACC_F64, ACC_MIXED = 0, 1, 2
 BAND_ARGMAX, BAND_FOLD = 0, 1
 BAND_NO_MATCH = -2 ** 31
 BAND_PREPARED = 1
@@ -49,6 +49,9 @@ PROTOTYPES = {
     'svamd_cross_correlate_1d_spectral': (_i, [_vp, _i64, _vp, _i64, _vp, _vp, _sz, _vp]),
     'svamd_scan_pairs': (_i, [_vp, _vp, _vp, _i64, _i, _d, _d, _i, _vp, _vp, _vp, _vp, _vp]),
     'svamd_scan_fold': (_i, [_vp, _vp, _vp, _vp, _i64, _d, _d, _vp, _vp, _vp, _vp]),
+    'svamd_scan_grid_workspace_bytes': (_sz, [_i64, _i64]),
+    'svamd_scan_grid': (_i, [_vp, _i64, _vp, _i64, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i64,
+                             _i, _d, _d, _d, _d, _i, _d, _vp, _vp, _vp, _sz, _vp]),
     'svamd_band_scan_u8_workspace_bytes': (_sz, [_i, _i, _i, _i]),
     'svamd_band_prepare_u8': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     'svamd_band_scan_u8': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _d, _d, _i, _i, _i,
@@ -82,23 +85,47 @@ def load_library():
             raise RuntimeError(
                 f'{LIB_PATH} is missing: build it with `make -C {_HERE}` '
                 '(hipcc --offload-arch=gfx950); there is no CPU fallback')
-        # libsvamd.so brings the system's HIP runtime along, PyTorch-ROCm its own copy; both
-        # live in the process.  The one PyTorch uses has to be initialised first: with the
-        # library (and the system runtime) loaded before PyTorch has touched the GPU, the
-        # library's first kernel launch fails with "no ROCm-capable device is detected".
-        try:
-            import torch
-            if torch.cuda.is_available():
-                torch.cuda.init()
-        except ImportError:
-            pass
+        # libsvamd.so asks the loader for "libamdhip64.so.7".  PyTorch-ROCm wheels bundle a
+        # copy of the HIP runtime whose file is called libamdhip64.so but whose SONAME is
+        # libamdhip64.so.7, so with PyTorch imported first (a plain import: no GPU call is
+        # needed) the loader hands the library that already-mapped copy and the process
+        # holds ONE runtime - streams, events and pointers pass freely between PyTorch and
+        # the library.  Loaded the other way round the library pulls in the system's
+        # runtime by its RUNPATH, PyTorch then maps its own file next to it, two HSA
+        # runtimes open the device and the library's first launch fails with "no
+        # ROCm-capable device is detected".
+        import torch        # noqa: F401  (before the library, for the reason above)
         lib = ctypes.CDLL(LIB_PATH)
+        _require_single_runtime()
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
         _lib = lib
     return _lib
+
+
+def hip_runtimes():
+    '''Paths of the HIP / HSA runtime files mapped into this process.'''
+    found = set()
+    try:
+        with open('/proc/self/maps') as maps:
+            for line in maps:
+                path = line.rsplit(None, 1)[-1]
+                if 'libamdhip64' in path or 'libhsa-runtime64' in path:
+                    found.add(path)
+    except OSError:         # pragma: no cover
+        pass
+    return sorted(found)
+
+
+def _require_single_runtime():
+    hip = [p for p in hip_runtimes() if 'libamdhip64' in p]
+    if len(hip) > 1:
+        raise RuntimeError(
+            'two HIP runtimes are mapped into this process (' + ', '.join(hip) + '): libsvamd.so or another '
+            'HIP library was loaded before PyTorch.  Import torch (or this package) first, so that every '
+            'library shares the runtime PyTorch ships; handles cannot cross between two runtimes')
 
 
 def torch_cuda():

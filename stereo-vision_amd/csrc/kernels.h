@@ -54,4 +54,14 @@ size_t fft_raw_workspace_bytes(int P, int Q);
 int fft_raw_correlate(const float *a, const float *b, int P, int Q, float *out, void *workspace,
                       hipStream_t stream);
 
+// scan_pairs.hip
+// The pair kernels behind svamd_scan_pairs (same arguments).  `list` / `list_count`
+// (float64 accumulation only): evaluate the pairs list[0 .. *list_count), a count that
+// an earlier kernel of the stream left on the device, with `list_grid` workgroups, and
+// leave each result at its pair's own index; without a list, pairs 0 .. npairs - 1.
+int launch_pairs(const double *tbase, const double *rbase, const int64_t *desc, int64_t npairs, int max_side,
+                 double min_std, double min_mean_diff, int acc_precision, double *out_max, int64_t *out_argmax,
+                 double *surfaces, const int64_t *surf_off, const int32_t *list, const int32_t *list_count,
+                 unsigned list_grid, hipStream_t st);
+
 }  // namespace svamd

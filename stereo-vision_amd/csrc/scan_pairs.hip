@@ -165,19 +165,25 @@ __global__ void __launch_bounds__(256)
 scan_pairs_kernel(const double *__restrict__ tbase, const double *__restrict__ rbase,
                   const PairDesc *__restrict__ desc, int64_t npairs, int max_side, double min_std,
                   double min_mean_diff, double *__restrict__ out_max, int64_t *__restrict__ out_argmax,
-                  double *__restrict__ surfaces, const int64_t *__restrict__ surf_off)
+                  double *__restrict__ surfaces, const int64_t *__restrict__ surf_off,
+                  const int32_t *__restrict__ list, const int32_t *__restrict__ list_count)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     __shared__ double red[17];
     __shared__ double red_d[4];
     __shared__ int red_i[8];   // up to 4 wavefronts per workgroup
     CT *Tb = reinterpret_cast<CT *>(smem_raw);
+    // With a list, the pairs list[0 .. *list_count) are evaluated (a count that an earlier
+    // kernel of the stream left on the device) and results land at the pairs' own indices.
+    if (list)
+        npairs = *list_count;
     // staging walks the boxes in sweeps as wide as the largest side (a power of two)
     const int cw_shift = max_side <= 8 ? 3 : max_side <= 16 ? 4 : max_side <= 32 ? 5 : 6;
     const int lx = threadIdx.x & ((1 << cw_shift) - 1), ly = threadIdx.x >> cw_shift;
     const int ystep = blockDim.x >> cw_shift;
 
-    for (int64_t p = blockIdx.x; p < npairs; p += gridDim.x) {
+    for (int64_t item = blockIdx.x; item < npairs; item += gridDim.x) {
+        const int64_t p = list ? (int64_t)list[item] : item;
         const PairDesc d = desc[p];
         const int th = (int)d.t_h, tw = (int)d.t_w, rh = (int)d.r_h, rw = (int)d.r_w;
         __syncthreads();  // LDS reuse across loop iterations
@@ -1063,21 +1069,14 @@ scan_fold_kernel(const double *__restrict__ corr_max, const uint8_t *__restrict_
 
 using namespace svamd;
 
-extern "C" int svamd_scan_pairs(const double *tbase, const double *rbase, const int64_t *desc,
-                                int64_t npairs, int max_side, double min_std, double min_mean_diff,
-                                int acc_precision, double *out_max, int64_t *out_argmax, double *surfaces,
-                                const int64_t *surf_off, void *stream)
+namespace svamd {
+
+int launch_pairs(const double *tbase, const double *rbase, const int64_t *desc, int64_t npairs, int max_side,
+                 double min_std, double min_mean_diff, int acc_precision, double *out_max, int64_t *out_argmax,
+                 double *surfaces, const int64_t *surf_off, const int32_t *list, const int32_t *list_count,
+                 unsigned list_grid, hipStream_t st)
 {
-    SV_REQUIRE(npairs >= 0, SVAMD_ERR_INVALID, "scan_pairs: negative pair count");
-    if (npairs == 0)
-        return SVAMD_OK;
-    SV_REQUIRE(tbase && rbase && desc && out_max, SVAMD_ERR_INVALID, "scan_pairs: NULL pointer");
-    SV_REQUIRE(!surfaces || surf_off, SVAMD_ERR_INVALID, "scan_pairs: surfaces given without offsets");
-    SV_REQUIRE(max_side > 0 && max_side <= SVAMD_PAIR_MAX_SIDE, SVAMD_ERR_LIMIT,
-               "scan_pairs: max_side %d outside 1..%d", max_side, SVAMD_PAIR_MAX_SIDE);
-    SV_REQUIRE(acc_precision == SVAMD_ACC_F32 || acc_precision == SVAMD_ACC_F64, SVAMD_ERR_INVALID,
-               "scan_pairs: unknown accumulation precision %d", acc_precision);
-    hipStream_t st = static_cast<hipStream_t>(stream);
+    const PairDesc *pd = reinterpret_cast<const PairDesc *>(desc);
     const size_t side4 = ((size_t)max_side + 3) & ~(size_t)3;
     // float64 kernel: tasks of 8 surface columns from 16 columns on (half the LDS reads per FMA), else of 4
     const int w64 = max_side >= 16 ? 8 : 4;
@@ -1087,8 +1086,7 @@ extern "C" int svamd_scan_pairs(const double *tbase, const double *rbase, const 
     // small windows get small workgroups
     const int tasks = max_side * ((max_side + w64 - 1) / w64);
     const int threads = tasks <= 64 ? 64 : tasks <= 128 ? 128 : 256;
-    const unsigned grid = (unsigned)(npairs < (1 << 20) ? npairs : (1 << 20));
-    const PairDesc *pd = reinterpret_cast<const PairDesc *>(desc);
+    const unsigned grid = list ? list_grid : (unsigned)(npairs < (1 << 20) ? npairs : (1 << 20));
     if (acc_precision == SVAMD_ACC_F32) {
         // columns per task: 8 unless 4 wastes fewer padded columns
         // Pairs with more than 32 tasks of 8 columns get a workgroup of two wavefronts
@@ -1141,18 +1139,40 @@ extern "C" int svamd_scan_pairs(const double *tbase, const double *rbase, const 
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
             }
             hipLaunchKernelGGL((scan_pairs_kernel<double, 8>), dim3(grid), dim3(threads), lds, st, tbase, rbase, pd,
-                               npairs, max_side, min_std, min_mean_diff, out_max, out_argmax, surfaces, surf_off);
+                               npairs, max_side, min_std, min_mean_diff, out_max, out_argmax, surfaces, surf_off,
+                               list, list_count);
         } else {
             if (lds > 64 * 1024) {
                 SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_pairs_kernel<double, 4>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
             }
             hipLaunchKernelGGL((scan_pairs_kernel<double, 4>), dim3(grid), dim3(threads), lds, st, tbase, rbase, pd,
-                               npairs, max_side, min_std, min_mean_diff, out_max, out_argmax, surfaces, surf_off);
+                               npairs, max_side, min_std, min_mean_diff, out_max, out_argmax, surfaces, surf_off,
+                               list, list_count);
         }
     }
     SV_LAUNCH_CHECK();
     return SVAMD_OK;
+}
+
+}  // namespace svamd
+
+extern "C" int svamd_scan_pairs(const double *tbase, const double *rbase, const int64_t *desc,
+                                int64_t npairs, int max_side, double min_std, double min_mean_diff,
+                                int acc_precision, double *out_max, int64_t *out_argmax, double *surfaces,
+                                const int64_t *surf_off, void *stream)
+{
+    SV_REQUIRE(npairs >= 0, SVAMD_ERR_INVALID, "scan_pairs: negative pair count");
+    if (npairs == 0)
+        return SVAMD_OK;
+    SV_REQUIRE(tbase && rbase && desc && out_max, SVAMD_ERR_INVALID, "scan_pairs: NULL pointer");
+    SV_REQUIRE(!surfaces || surf_off, SVAMD_ERR_INVALID, "scan_pairs: surfaces given without offsets");
+    SV_REQUIRE(max_side > 0 && max_side <= SVAMD_PAIR_MAX_SIDE, SVAMD_ERR_LIMIT,
+               "scan_pairs: max_side %d outside 1..%d", max_side, SVAMD_PAIR_MAX_SIDE);
+    SV_REQUIRE(acc_precision == SVAMD_ACC_F32 || acc_precision == SVAMD_ACC_F64, SVAMD_ERR_INVALID,
+               "scan_pairs: unknown accumulation precision %d", acc_precision);
+    return launch_pairs(tbase, rbase, desc, npairs, max_side, min_std, min_mean_diff, acc_precision, out_max,
+                        out_argmax, surfaces, surf_off, nullptr, nullptr, 0, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int svamd_scan_fold(const double *corr_max, const uint8_t *is_centre, const uint8_t *skip,

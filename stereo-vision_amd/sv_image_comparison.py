@@ -3,14 +3,18 @@ regions of a right image) on MI355X.
 
 Drop-in for the reference module of the same name (reference
 sv_image_comparison.py:1-380): same functions, arguments, module-level knobs,
-returned dict/list/tuple structure, exceptions and log lines.  The window and
-region enumeration stays on the host; every (template, region) correlation of
-a stage, its maximum and the per-window selection rule run on the GPU in two
-launches (libsvamd: svamd_scan_pairs, svamd_scan_fold).
+returned dict/list/tuple structure, exceptions and log lines.  The first stage
+tiles the image on a regular grid, so the host only works out the candidate
+positions along each axis; the (window, region) pairs are derived on the GPU
+from those two small tables, correlated, reduced and put through the
+per-window selection rule there, a band of window rows at a time (libsvamd:
+svamd_scan_grid), and the windows the caller gets back are built when they
+are looked at.  Later stages, which follow the few windows that moved, list
+their pairs on the host (svamd_scan_pairs, svamd_scan_fold).
 '''
 import contextlib
 import gc
-from collections.abc import Sequence
+from collections.abc import Mapping, Sequence
 
 import numpy as np
 
@@ -92,76 +96,6 @@ def _regions_for(centres, x_window, y_window, region_image):
     return regions, boxes
 
 
-def _axis_candidates(starts, window, span_hw, count, limit):
-    '''Along one image axis, for every window start: the candidate centres
-    (np.linspace, exactly as region_pairs builds them), their clipped integer
-    [begin, end) and whether get_window_boundaries would reject them.'''
-    centres = starts + window / 2
-    grid = np.linspace(centres - span_hw, centres + span_hw, count, axis=-1)        # [n, count]
-    half = window / 2
-    rejected = (grid + half <= 0) | (grid - half > limit)
-    begin = np.maximum(grid - half, 0).astype(np.int64)      # int() truncation of a value >= 0
-    end = np.minimum(grid + half, limit).astype(np.int64)
-    own_begin = np.maximum(centres - half, 0).astype(np.int64)
-    own_end = np.minimum(centres + half, limit).astype(np.int64)
-    own_rejected = (centres + half <= 0) | (centres - half > limit)
-    return dict(centres=centres.tolist(), grid=grid.tolist(), rejected=rejected.tolist(),
-                begin=begin.tolist(), end=end.tolist(), own_begin=own_begin.tolist(),
-                own_end=own_end.tolist(), own_rejected=own_rejected.tolist(),
-                centre_array=centres, grid_array=grid,
-                arrays=dict(rejected=rejected, begin=begin, end=end, own_begin=own_begin, own_end=own_end,
-                            own_rejected=own_rejected, at_centre=grid == centres[:, None]))
-
-
-def _stage0_boxes(ax, ay, xs, ys, x_window, y_window, image_width, image_height):
-    '''The boxes of _stage0_windows as arrays, without a Python loop over regions:
-    template boxes [windows, 4], region boxes [pairs, 4] (x_start, x_end, y_start,
-    y_end) in the order _stage0_windows lists the regions, the number of regions per
-    window, which pair is the window's own position, and the regions' centres
-    [pairs, 2].'''
-    X, Y = ax['arrays'], ay['arrays']
-    ncol, nx = X['begin'].shape
-    nrow, ny = Y['begin'].shape
-    slots = 1 + ny * nx
-    boxes = np.empty((nrow, ncol, slots, 4), dtype=np.int64)
-    valid = np.empty((nrow, ncol, slots), dtype=bool)
-    # slot 0: the window's own position
-    boxes[:, :, 0, 0] = X['own_begin'][None, :]
-    boxes[:, :, 0, 1] = X['own_end'][None, :]
-    boxes[:, :, 0, 2] = Y['own_begin'][:, None]
-    boxes[:, :, 0, 3] = Y['own_end'][:, None]
-    valid[:, :, 0] = ~(X['own_rejected'][None, :] | Y['own_rejected'][:, None])
-    # slots 1 + j * nx + i: the scheme grid, row by row
-    grid = boxes[:, :, 1:, :].reshape(nrow, ncol, ny, nx, 4)
-    grid[..., 0] = X['begin'][None, :, None, :]
-    grid[..., 1] = X['end'][None, :, None, :]
-    grid[..., 2] = Y['begin'][:, None, :, None]
-    grid[..., 3] = Y['end'][:, None, :, None]
-    valid[:, :, 1:] = ~(X['rejected'][None, :, None, :] | Y['rejected'][:, None, :, None] |
-                        (X['at_centre'][None, :, None, :] & Y['at_centre'][:, None, :, None])
-                        ).reshape(nrow, ncol, ny * nx)
-    counts = valid.sum(axis=2).ravel()
-    region_boxes = boxes[valid]
-    # the regions' centres, same order (what image_scan reports as the match position)
-    cx = np.empty((nrow, ncol, slots))
-    cy = np.empty((nrow, ncol, slots))
-    cx[:, :, 0] = ax['centre_array'][None, :]
-    cy[:, :, 0] = ay['centre_array'][:, None]
-    cx[:, :, 1:].reshape(nrow, ncol, ny, nx)[...] = ax['grid_array'][None, :, None, :]
-    cy[:, :, 1:].reshape(nrow, ncol, ny, nx)[...] = ay['grid_array'][:, None, :, None]
-    region_centres = np.stack([cx[valid], cy[valid]], axis=1)
-    centre = np.zeros(len(region_boxes), dtype=bool)
-    first = np.concatenate([[0], np.cumsum(counts)[:-1]])
-    own = valid[:, :, 0].ravel()
-    centre[first[own & (counts > 0)]] = True
-    template_boxes = np.empty((nrow, ncol, 4), dtype=np.int64)
-    template_boxes[:, :, 0] = xs[None, :]
-    template_boxes[:, :, 1] = np.minimum(xs + x_window, image_width)[None, :]
-    template_boxes[:, :, 2] = ys[:, None]
-    template_boxes[:, :, 3] = np.minimum(ys + y_window, image_height)[:, None]
-    return template_boxes.reshape(-1, 4), region_boxes, counts, centre, region_centres
-
-
 @contextlib.contextmanager
 def _gc_paused():
     '''Enumerating a stage creates hundreds of thousands of small dicts and tuples,
@@ -178,58 +112,19 @@ def _gc_paused():
 
 def _stage0_windows(template_image, region_image, x_window, y_window, scheme, scheme_shift_size,
                     window_overlap):
-    '''Windows of the first stage plus the arrays of _stage0_boxes (template boxes,
-    region boxes, regions per window, own-position flags).  Same enumeration as the
-    reference's double loop with region_pairs / get_window_boundaries per window,
-    but the candidate grids and their clipping are computed once per window
-    column and once per window row.'''
-    image_height, image_width = region_image.shape
-    if template_image.shape[0] != image_height or template_image.shape[1] != image_width:
-        raise Exception('Dimensions of template and region images must match')
-    if scheme[0] % 2 != 1 or scheme[1] % 2 != 1:
-        raise Exception('Scheme dimensions must be odd.')
-    x_stride = int(x_window * (1 - window_overlap))
-    y_stride = int(y_window * (1 - window_overlap))
-    if x_stride <= 0 or y_stride <= 0:
-        raise ValueError('window_overlap leaves a window stride of zero pixels')
-    x_span_hw = (scheme_shift_size[0] if scheme_shift_size[0] else x_window) * (scheme[0] - 1) / 2
-    y_span_hw = (scheme_shift_size[1] if scheme_shift_size[1] else y_window) * (scheme[1] - 1) / 2
-    xs = np.arange(0, image_width, x_stride)
-    ys = np.arange(0, image_height, y_stride)
-    ax = _axis_candidates(xs, x_window, x_span_hw, scheme[0], image_width)
-    ay = _axis_candidates(ys, y_window, y_span_hw, scheme[1], image_height)
-    size = (x_window, y_window)
-
-    # per window column / row: the candidates that survive clipping, as tuples
-    # (centre, begin, end, is the window's own centre)
-    x_cands = [[(g, b, e, g == c) for g, b, e, rej in zip(grid, begin, end, rejected) if not rej]
-               for c, grid, begin, end, rejected in zip(ax['centres'], ax['grid'], ax['begin'], ax['end'],
-                                                        ax['rejected'])]
-    y_cands = [[(g, b, e, g == c) for g, b, e, rej in zip(grid, begin, end, rejected) if not rej]
-               for c, grid, begin, end, rejected in zip(ay['centres'], ay['grid'], ay['begin'], ay['end'],
-                                                        ay['rejected'])]
-    x_own = list(zip(ax['own_rejected'], ax['own_begin'], ax['own_end'], ax['centres']))
-    y_own = list(zip(ay['own_rejected'], ay['own_begin'], ay['own_end'], ay['centres']))
-    stage_boxes = _stage0_boxes(ax, ay, xs, ys, x_window, y_window, image_width, image_height)
-    counts = stage_boxes[2].tolist()
+    '''The windows of a first stage as a dict, every window built (what
+    whole_image_search_regions returns; sequence_scan itself works from the grid's
+    arrays and builds windows only when they are read).  Same enumeration as the
+    reference's double loop with region_pairs / get_window_boundaries per window, but the
+    candidate grids and their clipping are computed once per window column and once per
+    window row.'''
+    grid = _Stage0Grid(template_image, region_image, x_window, y_window, scheme, scheme_shift_size,
+                       window_overlap)
     windows = {}
-    window_id = 0
-    for row, y in enumerate(ys.tolist()):
-        own_y = y_own[row]
-        y_cand = y_cands[row]
-        for column, x in enumerate(xs.tolist()):
-            own_x = x_own[column]
-            windows[window_id] = {
-                'row': row,
-                'column': column,
-                'centre': (own_x[3], own_y[3]),
-                'size': size,
-                'image_slice': template_image[y:y + y_window, x:x + x_window],
-                'target_regions': _Stage0Regions(region_image, own_x, own_y, x_cands[column], y_cand,
-                                                 counts[window_id]),
-            }
-            window_id += 1
-    return windows, stage_boxes
+    for window_id, window_info in _Stage0Windows(grid, None, None).items():
+        del window_info['stage_centres'], window_info['stage_sizes'], window_info['dp_x'], window_info['dp_y']
+        windows[window_id] = window_info
+    return windows, grid
 
 
 class _Stage0Regions(Sequence):
@@ -275,6 +170,236 @@ class _Stage0Regions(Sequence):
 
     def __repr__(self):
         return repr(self._list())
+
+
+# pairs per svamd_scan_grid call: bounds the device workspace (about 90 bytes per pair)
+GRID_CHUNK_PAIRS = 1 << 22
+
+
+class _Axis:
+    '''Candidate positions along one image axis for every window start on it: the
+    window's own position (entry 0) and the scheme's np.linspace grid, exactly as
+    region_pairs / get_window_boundaries compute them, as arrays.'''
+
+    def __init__(self, starts, window, span_hw, count, limit):
+        half = window / 2
+        self.starts, self.window, self.limit, self.count = starts, window, limit, count
+        self.centres = centres = starts + half
+        self.grid = grid = np.linspace(centres - span_hw, centres + span_hw, count, axis=-1)      # [n, count]
+        self.rejected = (grid + half <= 0) | (grid - half > limit)
+        self.begin = np.maximum(grid - half, 0).astype(np.int64)     # int() truncation of a value >= 0
+        self.end = np.minimum(grid + half, limit).astype(np.int64)
+        self.own_begin = np.maximum(centres - half, 0).astype(np.int64)
+        self.own_end = np.minimum(centres + half, limit).astype(np.int64)
+        self.own_rejected = (centres + half <= 0) | (centres - half > limit)
+        self.at_centre = grid == centres[:, None]
+        self.t_end = np.minimum(starts + window, limit)
+        kept = ~self.rejected
+        self.valid = kept.sum(axis=1)
+        self.centred = (kept & self.at_centre).sum(axis=1)
+        self._cands = {}
+
+    def tables(self, fields):
+        '''(cand, win) int32 tables of svamd_scan_grid for this axis.'''
+        n, count = self.grid.shape
+        kept = ~self.rejected
+        centred = kept & self.at_centre
+        cand = np.zeros((n, 1 + count, 5), dtype=np.int32)
+        cand[:, 0, 0], cand[:, 0, 1], cand[:, 0, 2] = self.own_begin, self.own_end, self.own_rejected
+        cand[:, 1:, 0], cand[:, 1:, 1] = self.begin, self.end
+        cand[:, 1:, 2] = self.rejected + 2 * self.at_centre
+        cand[:, 1:, 3] = np.cumsum(kept, axis=1) - kept
+        cand[:, 1:, 4] = np.cumsum(centred, axis=1) - centred
+        win = np.zeros((n, fields), dtype=np.int32)
+        own_ok = ~self.own_rejected
+        win[:, 0], win[:, 1], win[:, 2], win[:, 3], win[:, 4] = self.starts, self.t_end, own_ok, self.valid, self.centred
+        if fields == 8:
+            for k in (2, 3, 4):
+                win[:, k + 3] = np.cumsum(win[:, k]) - win[:, k]
+        return cand, win
+
+    def own(self, i):
+        '''(rejected, begin, end, centre) of window i's own position.'''
+        return (bool(self.own_rejected[i]), int(self.own_begin[i]), int(self.own_end[i]), float(self.centres[i]))
+
+    def candidates(self, i):
+        '''Window i's surviving grid candidates as (centre, begin, end, is the own centre).'''
+        got = self._cands.get(i)
+        if got is None:
+            c = float(self.centres[i])
+            got = self._cands[i] = [
+                (g, b, e, g == c) for g, b, e, rej in zip(self.grid[i].tolist(), self.begin[i].tolist(),
+                                                          self.end[i].tolist(), self.rejected[i].tolist()) if not rej]
+        return got
+
+
+class _Stage0Grid:
+    '''Geometry of a first stage: the per-axis candidates and what follows from them.'''
+
+    def __init__(self, template_image, region_image, x_window, y_window, scheme, scheme_shift_size, window_overlap):
+        image_height, image_width = region_image.shape
+        if template_image.shape[0] != image_height or template_image.shape[1] != image_width:
+            raise Exception('Dimensions of template and region images must match')
+        if scheme[0] % 2 != 1 or scheme[1] % 2 != 1:
+            raise Exception('Scheme dimensions must be odd.')
+        x_stride = int(x_window * (1 - window_overlap))
+        y_stride = int(y_window * (1 - window_overlap))
+        if x_stride <= 0 or y_stride <= 0:
+            raise ValueError('window_overlap leaves a window stride of zero pixels')
+        x_span_hw = (scheme_shift_size[0] if scheme_shift_size[0] else x_window) * (scheme[0] - 1) / 2
+        y_span_hw = (scheme_shift_size[1] if scheme_shift_size[1] else y_window) * (scheme[1] - 1) / 2
+        self.template_image, self.region_image = template_image, region_image
+        self.size = (x_window, y_window)
+        self.ax = _Axis(np.arange(0, image_width, x_stride), x_window, x_span_hw, scheme[0], image_width)
+        self.ay = _Axis(np.arange(0, image_height, y_stride), y_window, y_span_hw, scheme[1], image_height)
+        self.ncol, self.nrow = len(self.ax.starts), len(self.ay.starts)
+        self.nwin = self.ncol * self.nrow
+        ax, ay = self.ax, self.ay
+        own_x, own_y = ~ax.own_rejected, ~ay.own_rejected
+        # pairs per window row, and each row's first pair in the whole stage
+        per_row = (own_y * int(own_x.sum()) + ay.valid * int(ax.valid.sum()) - ay.centred * int(ax.centred.sum()))
+        self.row_first = np.concatenate([[0], np.cumsum(per_row.astype(np.int64))])
+        self.max_side = int(max(x_window, y_window, 1))
+
+    def pair_count(self, row, column):
+        ax, ay = self.ax, self.ay
+        return int((not ax.own_rejected[column] and not ay.own_rejected[row]) +
+                   ay.valid[row] * ax.valid[column] - ay.centred[row] * ax.centred[column])
+
+    def row_chunks(self, row_begin, row_end, limit):
+        '''[begin, end) runs of window rows whose pairs stay below `limit` (single rows may exceed it).'''
+        first = self.row_first
+        chunks, begin = [], row_begin
+        while begin < row_end:
+            end = int(np.searchsorted(first, first[begin] + limit, side='right')) - 1
+            end = min(max(end, begin + 1), row_end)
+            chunks.append((begin, end))
+            begin = end
+        return chunks
+
+    def tables(self):
+        '''The per-axis tables of svamd_scan_grid as numpy arrays.'''
+        xcand, xwin = self.ax.tables(8)
+        ycand, ywin = self.ay.tables(5)
+        return dict(row_first=self.row_first, xcand=xcand, xwin=xwin, ycand=ycand, ywin=ywin)
+
+    def run(self, left_dev, right_dev, threshold):
+        '''Every window of the stage through svamd_scan_grid.  Returns per window the selected
+        candidate slot (-1: none) and its correlation, as numpy arrays.  With an initialised
+        torch.distributed process group every rank takes a band of window rows and the
+        per-window results are all-gathered.'''
+        rank, size = sharding.world()
+        sharded = size > 1 and self.nrow >= size
+        row_begin, row_end = sharding.shard_range(self.nrow, rank, size) if sharded else (0, self.nrow)
+        slot, val = _scan_grid_rows(left_dev, right_dev, self, self.tables(), row_begin, row_end, threshold)
+        if sharded:
+            # shares are whole window rows: gathered as rows of ncol windows
+            slot = sharding.all_gather_concat(slot.reshape(-1, self.ncol), self.nrow).ravel()
+            val = sharding.all_gather_concat(val.reshape(-1, self.ncol), self.nrow).ravel()
+        return slot, val
+
+    def positions(self, slot):
+        '''Per window: the centre of the selected candidate (the window's own centre where
+        nothing was selected), as two float64 arrays.'''
+        nx = self.ax.count
+        column = np.tile(np.arange(self.ncol), self.nrow)
+        row = np.repeat(np.arange(self.nrow), self.ncol)
+        on_grid = slot > 0
+        g = np.where(on_grid, slot - 1, 0)
+        pos_x = np.where(on_grid, self.ax.grid[column, g % nx], self.ax.centres[column])
+        pos_y = np.where(on_grid, self.ay.grid[row, g // nx], self.ay.centres[row])
+        return pos_x, pos_y
+
+
+class _Stage0Windows(Mapping):
+    '''The dict of first-stage windows that sequence_scan returns, built window by window
+    when it is read.  A dense scan has millions of windows; the scan itself works from
+    arrays, and a caller that walks the result pays for the dicts it looks at.  Behaves as
+    the dict it stands for (ids 0 .. n - 1 in order); a window, once built, is kept, so
+    that later stages and callers see each other's changes to it as they would in a dict.'''
+
+    def __init__(self, grid, dp_x, dp_y):
+        self._grid, self._dp_x, self._dp_y, self._built = grid, dp_x, dp_y, {}
+
+    def __len__(self):
+        return self._grid.nwin
+
+    def __iter__(self):
+        return iter(range(self._grid.nwin))
+
+    def __contains__(self, window_id):
+        return isinstance(window_id, (int, np.integer)) and 0 <= window_id < self._grid.nwin
+
+    def __getitem__(self, window_id):
+        if window_id not in self:
+            raise KeyError(window_id)
+        window_id = int(window_id)
+        info = self._built.get(window_id)
+        if info is None:
+            g = self._grid
+            row, column = divmod(window_id, g.ncol)
+            x, y = int(g.ax.starts[column]), int(g.ay.starts[row])
+            own_x, own_y = g.ax.own(column), g.ay.own(row)
+            centre = (own_x[3], own_y[3])
+            info = self._built[window_id] = {
+                'row': row,
+                'column': column,
+                'centre': centre,
+                'size': g.size,
+                'image_slice': g.template_image[y:y + g.size[1], x:x + g.size[0]],
+                'target_regions': _Stage0Regions(g.region_image, own_x, own_y, g.ax.candidates(column),
+                                                 g.ay.candidates(row), g.pair_count(row, column)),
+                'stage_centres': [centre],
+                'stage_sizes': [g.size],
+                'dp_x': float(self._dp_x[window_id]) if self._dp_x is not None else None,
+                'dp_y': float(self._dp_y[window_id]) if self._dp_y is not None else None,
+            }
+        return info
+
+    def moved(self):
+        '''ids of the windows with a displacement, ascending.'''
+        return np.flatnonzero((self._dp_x != 0) | (self._dp_y != 0)).tolist()
+
+    def __repr__(self):
+        return repr(dict(self.items()))
+
+
+def _scan_grid_rows(left_dev, right_dev, grid, tables, row_begin, row_end, threshold):
+    '''Window rows [row_begin, row_end) of a first stage on the GPU: the tables go up in one
+    copy, the rows run through svamd_scan_grid in chunks of at most GRID_CHUNK_PAIRS pairs
+    (one workspace, reused in stream order) and two small arrays come back: per window of
+    those rows the selected candidate slot (-1: none) and its correlation.'''
+    torch = nv.torch_cuda()
+    if SCAN_PRECISION not in ('mixed', 'fp64', 'fp32'):
+        raise ValueError(f'unknown SCAN_PRECISION {SCAN_PRECISION!r}')
+    precision = {'mixed': nv.ACC_MIXED, 'fp64': nv.ACC_F64, 'fp32': nv.ACC_F32}[SCAN_PRECISION]
+    row_first = tables['row_first']
+    # one upload: the int64 row offsets first, then the four int32 tables, each 256-byte aligned
+    parts = [row_first.view(np.int32)] + [tables[k].ravel() for k in ('xcand', 'xwin', 'ycand', 'ywin')]
+    offsets = np.cumsum([0] + [(p.size + 63) // 64 * 64 for p in parts])
+    packed = np.zeros(int(offsets[-1]), dtype=np.int32)
+    for part, at in zip(parts, offsets):
+        packed[at:at + part.size] = part
+    d_tab = nv.to_device(packed)
+    t_row, t_xc, t_xw, t_yc, t_yw = (nv._vp(d_tab.data_ptr() + 4 * int(at)) for at in offsets[:-1])
+    chunks = grid.row_chunks(row_begin, row_end, GRID_CHUNK_PAIRS)
+    lib = nv.load_library()
+    nbytes = max((lib.svamd_scan_grid_workspace_bytes((e - b) * grid.ncol, int(row_first[e] - row_first[b]))
+                  for b, e in chunks), default=0)
+    ws = nv.workspace(nbytes)
+    best_slot = nv.empty(grid.nwin, torch.int32)
+    best_val = nv.empty(grid.nwin, torch.float64)
+    stream = nv.stream_ptr()
+    min_std = float(correlation_spectral.MIN_ST_DEV)
+    min_diff = float(correlation_spectral.MIN_MEAN_DIFF)
+    for begin, end in chunks:
+        nv.call('svamd_scan_grid', nv.ptr(left_dev), left_dev.shape[1], nv.ptr(right_dev), right_dev.shape[1],
+                t_xc, t_xw, grid.ncol, grid.ax.count, t_yc, t_yw, grid.nrow, grid.ay.count, t_row, begin, end,
+                int(row_first[end] - row_first[begin]), grid.max_side, min_std, min_diff, float(threshold),
+                float(CENTRE_TOL), precision, float(GUARD_BAND), nv.ptr(best_slot), nv.ptr(best_val), nv.ptr(ws),
+                nbytes, stream)
+    w0, w1 = row_begin * grid.ncol, row_end * grid.ncol
+    return best_slot[w0:w1].cpu().numpy(), best_val[w0:w1].cpu().numpy()
 
 
 def whole_image_search_regions(template_image, region_image, x_window, y_window,
@@ -491,15 +616,6 @@ class _StageBatch:
         self.template_boxes, self.region_boxes, self.centre, self.offsets = [], [], [], [0]
         self._desc = None
 
-    def add_arrays(self, template_boxes, region_boxes, counts, centre):
-        '''A whole stage at once, from the arrays of _stage0_boxes.'''
-        assert not self.template_boxes
-        self.template_boxes = template_boxes
-        self.region_boxes = region_boxes
-        self.centre = centre
-        self.offsets = np.concatenate([[0], np.cumsum(counts)]).tolist()
-        self._desc = None
-
     def add(self, template_box, centre, regions, region_boxes):
         self.template_boxes.append(template_box)
         self.region_boxes.extend(region_boxes)
@@ -562,7 +678,7 @@ def _sequence_scan(left_image, right_image, scan_config):
     for stage, stage_config in enumerate(scan_config):
         windows = {}
         if stage == 0:
-            windows, stage_boxes = _stage0_windows(
+            grid = _Stage0Grid(
                 template_image=left_image,
                 region_image=right_image,
                 x_window=stage_config['window_width'],
@@ -572,41 +688,41 @@ def _sequence_scan(left_image, right_image, scan_config):
                 window_overlap=stage_config['window_overlap'],
             )
             threshold = stage_config['correlation_threshold']
-            for window_info in windows.values():
-                window_info['stage_centres'] = [window_info['centre']]
-                window_info['stage_sizes'] = [window_info['size']]
-            batch = _StageBatch(image_width, right_image.shape[1])
-            batch.add_arrays(*stage_boxes[:4])
-            if batched and batch.max_side() <= nv.PAIR_MAX_SIDE:
-                best_pair, best_val = batch.run(*resident(), threshold)
-                # the selected region's centre straight from the centre array: the region
-                # dicts themselves are built only if somebody reads them
-                region_centres = stage_boxes[4]
-                matched = best_pair >= 0
-                chosen = region_centres[np.where(matched, best_pair, 0)].tolist()
-                values = best_val.tolist()
+            if batched and grid.max_side <= nv.PAIR_MAX_SIDE:
+                slot, best_val = grid.run(*resident(), threshold)
+                pos_x, pos_y = grid.positions(slot)
+                dp_x = pos_x - np.tile(grid.ax.centres, grid.nrow)
+                dp_y = pos_y - np.repeat(grid.ay.centres, grid.ncol)
+                windows = _Stage0Windows(grid, dp_x, dp_y)
                 log_all = LOG_WINDOW_SUMMARY == True          # noqa: E712 (the reference compares this way)
-                for i, (window_id, window_info) in enumerate(windows.items()):
-                    centre = window_info['centre']
-                    if matched[i]:
-                        pos, val = tuple(chosen[i]), values[i]
-                    else:
-                        pos, val = centre, 0
-                    dp_x, dp_y = pos[0] - centre[0], pos[1] - centre[1]
-                    if log_all or dp_x != 0 or dp_y != 0:
+                if LOG_WINDOW_SUMMARY:
+                    for window_id in (range(grid.nwin) if log_all else windows.moved()):
+                        row, column = divmod(window_id, grid.ncol)
+                        centre = (float(grid.ax.centres[column]), float(grid.ay.centres[row]))
+                        if slot[window_id] >= 0:
+                            pos, val = (float(pos_x[window_id]), float(pos_y[window_id])), float(best_val[window_id])
+                        else:
+                            pos, val = centre, 0
                         _log_summary(window_id, centre, val, pos)
-                    window_info['dp_x'] = dp_x
-                    window_info['dp_y'] = dp_y
             else:
+                windows = _stage0_windows(left_image, right_image, *grid.size, tuple(stage_config['scheme']),
+                                          tuple(stage_config['scheme_shift_size']),
+                                          stage_config['window_overlap'])[0]
                 for window_id, window_info in windows.items():
+                    window_info['stage_centres'] = [window_info['centre']]
+                    window_info['stage_sizes'] = [window_info['size']]
                     pos, _ = _image_scan_pairwise(window_info, window_id, threshold)
                     window_info['dp_x'] = pos[0] - window_info['centre'][0]
                     window_info['dp_y'] = pos[1] - window_info['centre'][1]
         else:
             factor = stage_config['factor']
             region_boxes = {}
-            for window_id, window_info in seq_results[stage - 1].items():
-                # windows without a displacement in the previous stage drop out
+            previous = seq_results[stage - 1]
+            # windows without a displacement in the previous stage drop out (a first stage
+            # knows them from its arrays, without building the others)
+            candidates = previous.moved() if isinstance(previous, _Stage0Windows) else previous
+            for window_id in candidates:
+                window_info = previous[window_id]
                 if (window_info['dp_x'] == 0 and window_info['dp_y'] == 0) or \
                         len(window_info['stage_sizes']) < stage:
                     continue

@@ -86,6 +86,61 @@ def oracle_select_local(tbase, rbase, desc, is_centre, skip, win_off, threshold,
     return best_pair, best_val
 
 
+def enumerate_grid_pairs(tables, ncol, nx, nrow, ny, row_begin, row_end, left_pitch, right_pitch):
+    '''What libsvamd's grid_enumerate_kernel derives from the per-axis tables, thread
+    by thread, in numpy: (desc [P, 8], is_centre [P], pair_slot [P], win_off [nwin + 1])
+    for window rows [row_begin, row_end).  Raises if two candidates claim one pair
+    index or one stays unclaimed, i.e. if the tables do not add up.'''
+    row_first, xcand, xwin = tables['row_first'], tables['xcand'], tables['xwin']
+    ycand, ywin = tables['ycand'], tables['ywin']
+    npairs = int(row_first[row_end] - row_first[row_begin])
+    nwin = (row_end - row_begin) * ncol
+    desc = np.full((npairs, 8), -1, dtype=np.int64)
+    is_centre = np.zeros(npairs, dtype=np.uint8)
+    pair_slot = np.full(npairs, -1, dtype=np.int32)
+    win_off = np.zeros(nwin + 1, dtype=np.int64)
+    for w in range(nwin):
+        r, c = row_begin + w // ncol, w % ncol
+        xw, yw = xwin[c].astype(np.int64), ywin[r].astype(np.int64)
+        own_ok = int(xw[2] & yw[2])
+        first = int(row_first[r] - row_first[row_begin] + yw[2] * xw[5] + yw[3] * xw[6] - yw[4] * xw[7])
+        win_off[w] = first
+        if w == nwin - 1:
+            win_off[nwin] = first + own_ok + yw[3] * xw[3] - yw[4] * xw[4]
+        for slot in range(1 + nx * ny):
+            if slot == 0:
+                xc, yc, valid, rank = xcand[c, 0], ycand[r, 0], own_ok != 0, 0
+            else:
+                iy, ix = divmod(slot - 1, nx)
+                xc, yc = xcand[c, 1 + ix].astype(np.int64), ycand[r, 1 + iy].astype(np.int64)
+                xrej, yrej, xac, yac = xc[2] & 1, yc[2] & 1, xc[2] & 2, yc[2] & 2
+                valid = not (xrej or yrej) and not (xac and yac)
+                rank = int(own_ok + yc[3] * xw[3] + xc[3] - (yc[4] * xw[4] + (xc[4] if yac else 0)))
+            if not valid:
+                continue
+            p = first + rank
+            assert 0 <= p < npairs and pair_slot[p] == -1, 'two candidates share a pair index'
+            desc[p] = (yw[0] * left_pitch + xw[0], left_pitch, yw[1] - yw[0], xw[1] - xw[0],
+                       yc[0] * right_pitch + xc[0], right_pitch, yc[1] - yc[0], xc[1] - xc[0])
+            is_centre[p] = slot == 0
+            pair_slot[p] = slot
+    assert (pair_slot >= 0).all(), 'a pair index stays unclaimed'
+    return desc, is_centre, pair_slot, win_off
+
+
+def oracle_scan_grid_rows(left, right, grid, tables, row_begin, row_end, threshold):
+    '''Stand-in for sv_image_comparison._scan_grid_rows (the svamd_scan_grid call) with the
+    same contract: pairs from the tables as the device derives them, correlations and
+    the selection rule from the oracle.'''
+    desc, is_centre, pair_slot, win_off = enumerate_grid_pairs(
+        tables, grid.ncol, grid.ax.count, grid.nrow, grid.ay.count, row_begin, row_end, left.shape[1],
+        right.shape[1])
+    skip = (desc[:, 6] <= 0) | (desc[:, 7] <= 0)
+    best_pair, best_val = oracle_select_local(left, right, desc, is_centre, skip, win_off, threshold, grid.max_side)
+    slot = np.where(best_pair >= 0, pair_slot[np.maximum(best_pair, 0)], -1).astype(np.int32)
+    return slot, np.where(best_pair >= 0, best_val, 0.0)
+
+
 def check_band_fold_against_g14(band_scan_fold):
     '''g14_dense_spatial_fold: the reference's sequence_scan (its own selection rule)
     over its spatial correlator at full overlap, on a dense 31 x 31, 25-offset

@@ -10,7 +10,7 @@ import json
 import numpy as np
 import pytest
 
-from helpers import golden, oracle_select_local
+from helpers import golden, oracle_scan_grid_rows, oracle_select_local
 
 
 @pytest.fixture()
@@ -18,6 +18,7 @@ def host_only(monkeypatch, oracle):
     import _native as nv
     import sv_image_comparison as v
     monkeypatch.setattr(v, '_select_local', oracle_select_local)
+    monkeypatch.setattr(v, '_scan_grid_rows', oracle_scan_grid_rows)
     monkeypatch.setattr(nv, 'to_device', lambda a: np.ascontiguousarray(a))
     return v
 
@@ -72,6 +73,83 @@ def test_window_dicts_match_reference_layout(host_only):
     # bottom-right windows are truncated by slicing
     last = windows[len(windows) - 1]
     assert last['image_slice'].shape[0] <= 10 and last['image_slice'].shape[1] <= 12
+
+
+def test_grid_tables_enumerate_the_reference_pairs(host_only):
+    '''The per-axis tables handed to svamd_scan_grid, expanded the way the device
+    expands them, give exactly the (template, region) boxes, in exactly the order, of
+    the reference's per-window enumeration (region_pairs + get_window_boundaries,
+    sv_image_comparison.py:119-191) - including candidates that leave the image, empty
+    boxes at the border, truncated windows and schemes whose grid misses the centre.'''
+    from helpers import enumerate_grid_pairs
+    v = host_only
+    rng = np.random.default_rng(11)
+    cases = 0
+    for _ in range(60):
+        h, w = int(rng.integers(20, 48)), int(rng.integers(20, 60))
+        ww, wh = int(rng.integers(4, 14)), int(rng.integers(4, 14))
+        scheme = (int(rng.choice([1, 3, 5, 9])), int(rng.choice([1, 3, 5])))
+        shift = (int(rng.choice([0, 1, 3, 25])), int(rng.choice([0, 1, 2, 30])))
+        overlap = float(rng.choice([0, 0.3, 0.5, 0.75]))
+        if int(ww * (1 - overlap)) <= 0 or int(wh * (1 - overlap)) <= 0:
+            continue
+        left, right = rng.random((h, w)), rng.random((h, w))
+        grid = v._Stage0Grid(left, right, ww, wh, scheme, shift, overlap)
+        tables = grid.tables()
+        begin, end = sorted(int(i) for i in rng.integers(0, grid.nrow + 1, size=2))
+        desc, is_centre, pair_slot, win_off = enumerate_grid_pairs(
+            tables, grid.ncol, scheme[0], grid.nrow, scheme[1], begin, end, w, w)
+        p = 0
+        for k, window_id in enumerate(range(begin * grid.ncol, end * grid.ncol)):
+            row, column = divmod(window_id, grid.ncol)
+            x, y = int(grid.ax.starts[column]), int(grid.ay.starts[row])
+            centre = (x + ww / 2, y + wh / 2)
+            assert win_off[k] == p
+            for cx, cy in v.region_pairs(centre[0], ww, centre[1], wh, scheme, shift):
+                box = v.get_window_boundaries(cx, cy, ww, wh, w, h)
+                if box is None:
+                    continue
+                x0, x1, y0, y1 = box
+                assert tuple(desc[p]) == (y * w + x, w, min(y + wh, h) - y, min(x + ww, w) - x,
+                                          y0 * w + x0, w, y1 - y0, x1 - x0)
+                assert bool(is_centre[p]) == ((cx, cy) == centre)
+                slot = int(pair_slot[p])
+                got = centre if slot == 0 else (grid.ax.grid[column, (slot - 1) % scheme[0]],
+                                                grid.ay.grid[row, (slot - 1) // scheme[0]])
+                assert got == (cx, cy)
+                p += 1
+            assert grid.pair_count(row, column) == p - win_off[k]
+        assert win_off[-1] == p == int(grid.row_first[end] - grid.row_first[begin])
+        cases += 1
+    assert cases > 30
+
+
+def test_first_stage_windows_are_built_on_demand(host_only):
+    '''sequence_scan's first-stage result behaves as the dict it stands for, builds a
+    window when it is read and keeps it.'''
+    v = host_only
+    rng = np.random.default_rng(3)
+    left = rng.random((30, 44))
+    right = np.roll(left, 2, axis=1)
+    cfg = [{'window_width': 10, 'window_height': 10, 'scheme': [5, 1], 'scheme_shift_size': [1, 0],
+            'window_overlap': 0, 'correlation_threshold': 0.5}]
+    with contextlib.redirect_stdout(io.StringIO()):
+        windows = v.sequence_scan(left, right, cfg)[0]
+    assert len(windows) == 15 and list(windows) == list(range(15)) and 3 in windows and 15 not in windows
+    assert not windows._built
+    w = windows[5]
+    assert windows[5] is w and list(windows._built) == [5]
+    assert list(w) == ['row', 'column', 'centre', 'size', 'image_slice', 'target_regions', 'stage_centres',
+                       'stage_sizes', 'dp_x', 'dp_y']
+    assert (w['row'], w['column'], w['centre'], w['size']) == (1, 0, (5.0, 15.0), (10, 10))
+    assert w['stage_centres'] == [w['centre']] and w['stage_sizes'] == [(10, 10)]
+    assert type(w['dp_x']) is float and np.shares_memory(w['image_slice'], left)
+    moved = [i for i, info in windows.items() if info['dp_x'] or info['dp_y']]
+    assert moved == windows.moved() and moved
+    assert sum(windows[i]['dp_x'] == 2.0 and windows[i]['dp_y'] == 0.0 for i in moved) >= 9
+    with pytest.raises(KeyError):
+        windows[15]
+    assert windows.get(99) is None and dict(windows) == {i: windows[i] for i in range(15)}
 
 
 def test_get_window_boundaries_edges(host_only):

@@ -11,7 +11,7 @@ import numpy as np
 import torch.multiprocessing as mp
 
 import helpers  # noqa: F401
-from helpers import oracle_select_local
+from helpers import oracle_scan_grid_rows, oracle_select_local
 
 
 def free_port():
@@ -37,6 +37,7 @@ def worker(rank, size, port, out_dir):
         assert np.array_equal(got, full)
 
         v._select_local = oracle_select_local
+        v._scan_grid_rows = oracle_scan_grid_rows
         nv.to_device = lambda a: np.ascontiguousarray(a)     # "resident" images stay numpy here
         rng = np.random.default_rng(7)
         left = rng.random((40, 66))
