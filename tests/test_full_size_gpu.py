@@ -212,3 +212,57 @@ def test_long_1d_correlation_sampled(oracle):
     for i in rng.integers(0, 2 * n - 1, size=40):
         want = float(np.sum(a0 * (padded[i:i + n] - b.mean())) / n)
         assert abs(float(got[i]) - want) <= 1e-5 * scale, int(i)
+
+
+def test_dense_scan_through_sequence_scan(oracle):
+    '''The dense configuration through the reference's own entry point: 31 x 31 windows at
+    every pixel of a 256 x 256 pair, 257 candidate offsets each (16.7 million circular
+    pairs, derived on the device a band of window rows at a time).  The oracle needs
+    about a millisecond per pair, so it checks a sample of windows - corners, borders,
+    interior - with its own enumeration and selection rule: position exactly,
+    correlation to 1e-11.  Over all windows: the planted shift is found wherever the
+    window and its match lie inside the image, and the result does not depend on how
+    the rows were cut into chunks.'''
+    import contextlib
+    import io
+    import sv_image_comparison as v
+    from oracle import ncc_oracle
+    rng = np.random.default_rng(21)
+    n, win, shift = 256, 31, 9
+    left = rng.integers(0, 256, size=(n, n), dtype=np.uint8) / 255.0
+    right = np.roll(left, shift, axis=1)
+    cfg = [{'window_width': win, 'window_height': win, 'scheme': [257, 1], 'scheme_shift_size': [1, 0],
+            'window_overlap': 0.96, 'correlation_threshold': 0.5}]
+    saved = v.LOG_WINDOW_SUMMARY, v.GRID_CHUNK_PAIRS
+    v.LOG_WINDOW_SUMMARY = False
+    try:
+        results = []
+        for chunk in (1 << 20, 3_000_017):
+            v.GRID_CHUNK_PAIRS = chunk
+            with contextlib.redirect_stdout(io.StringIO()):
+                windows = v.sequence_scan(left, right, cfg)[0]
+            results.append((windows._dp_x.copy(), windows._dp_y.copy()))
+    finally:
+        v.LOG_WINDOW_SUMMARY, v.GRID_CHUNK_PAIRS = saved
+    assert len(windows) == n * n
+    assert np.array_equal(results[0][0], results[1][0]) and np.array_equal(results[0][1], results[1][1])
+    dp_x = results[0][0].reshape(n, n)
+    assert not results[0][1].any()
+    # windows that are whole and whose match is whole: the shift is exact there
+    assert (dp_x[:n - win + 1, :n - win + 1 - shift] == shift).all()
+    sample = [0, n - 1, n * (n - 1), n * n - 1, 5 * n + 128, 128 * n + 3, 128 * n + n - 2, (n - 2) * n + 77]
+    sample += [int(i) for i in rng.integers(0, n * n, size=24)]
+    for window_id in sample:
+        row, column = divmod(window_id, n)
+        centre = (column + win / 2, row + win / 2)
+        regions = []
+        for c in ncc_oracle.candidate_centres(centre[0], win, centre[1], win, (257, 1), (1, 0)):
+            box = ncc_oracle.window_box(c[0], c[1], win, win, n, n)
+            if box is not None:
+                regions.append((c, right[box[2]:box[3], box[0]:box[1]]))
+        pos, best = ncc_oracle._fold(left[row:row + win, column:column + win], centre, regions, 0.5,
+                                     ncc_oracle.CENTRE_TOL)
+        info = windows[window_id]
+        assert (info['row'], info['column'], info['centre']) == (row, column, centre)
+        assert len(info['target_regions']) == len(regions)
+        assert (info['dp_x'], info['dp_y']) == (pos[0] - centre[0], pos[1] - centre[1]), window_id

@@ -1292,3 +1292,67 @@ def test_driver_image_comparison_downsampled(mods, oracle, tmp_path, monkeypatch
         assert np.array_equal(got, grid), got_key
     assert np.count_nonzero(np.array(saved['dp_x_grid'])) > 0
 
+
+
+# ---- process-level behaviour of the binding ---------------------------------------
+def test_first_call_of_a_fresh_process_is_the_spectral_correlation():
+    '''A process whose very first use of the package is cross_correlate_2d_spectral (no
+    torch import of its own, no other call before): the library must come up on the HIP
+    runtime PyTorch ships - one runtime in the process - and the call must work.'''
+    import subprocess
+    import sys
+    from helpers import PKG
+    code = (
+        'import sys; sys.path.insert(0, %r)\n'
+        'import numpy as np\n'
+        'import correlation_spectral as s\n'
+        'rng = np.random.default_rng(0)\n'
+        't, r = rng.random((20, 24)), rng.random((20, 24))\n'
+        'got = s.cross_correlate_2d_spectral(t, r)\n'
+        'tn = (t - t.mean()) / (t.std() * t.size); rn = (r - r.mean()) / r.std()\n'
+        'want = np.real(np.fft.ifft2(np.conj(np.fft.fft2(tn)) * np.fft.fft2(rn)))\n'
+        'import _native\n'
+        'hip = [p for p in _native.hip_runtimes() if "libamdhip64" in p]\n'
+        'assert len(hip) == 1, hip\n'
+        'assert np.abs(got - want).max() < 1e-12\n'
+        'print("fresh ok")\n') % PKG
+    done = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
+    assert done.returncode == 0 and 'fresh ok' in done.stdout, done.stderr[-2000:]
+
+
+def test_loading_the_library_before_torch_is_refused():
+    '''The order that gives the process two HIP runtimes (libsvamd.so mapped before
+    PyTorch) is reported by the binding instead of failing at the first launch.'''
+    import subprocess
+    import sys
+    from helpers import PKG
+    code = (
+        'import ctypes, os, sys; sys.path.insert(0, %r)\n'
+        'ctypes.CDLL(os.path.join(%r, "libsvamd.so"))\n'
+        'import _native\n'
+        'try:\n'
+        '    _native.load_library()\n'
+        'except RuntimeError as exc:\n'
+        '    assert "two HIP runtimes" in str(exc), exc\n'
+        '    print("refused")\n') % (PKG, PKG)
+    done = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
+    assert done.returncode == 0 and 'refused' in done.stdout, (done.stdout, done.stderr[-2000:])
+
+
+def test_entry_points_follow_the_current_torch_stream(mods):
+    '''Calls made under torch.cuda.stream(side stream) run on that stream (the binding
+    hands the library torch's current stream) and give the same results as on the
+    default stream.'''
+    import torch
+    rng = np.random.default_rng(5)
+    t, r = rng.random((24, 30)), rng.random((24, 30))
+    v1, v2 = rng.random(3000), rng.random(3000)
+    want_2d = mods['s'].cross_correlate_2d_spectral(t, r)
+    want_1d = quiet(mods['c'].cross_correlate_1d, v1, v2)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        assert mods['n'].stream_ptr().value == side.cuda_stream
+        got_2d = mods['s'].cross_correlate_2d_spectral(t, r)
+        got_1d = quiet(mods['c'].cross_correlate_1d, v1, v2)
+    side.synchronize()
+    assert np.array_equal(got_2d, want_2d) and np.array_equal(got_1d, want_1d)
