@@ -20,9 +20,11 @@ measurement gives every rank a pair of its own (weak scaling) and is reported as
 
 metric: NCC window evaluations per second, an evaluation being one (window,
 offset) score = 2 * 31 * 31 algorithmic float32 flops of cross term.
-roofline: the band kernel alone on rank 0, timed with HIP events on its stream,
-against the FP32 vector-ALU peak.  cpu_baseline (N = 1 only): the C oracle
-(OpenMP, every core granted) on a crop, plus one-thread numpy rows.
+roofline: the band kernel alone, timed with HIP events on its stream on every rank
+(the slowest rank's figures are reported), against the FP32 vector-ALU peak.
+cpu_baseline (N = 1 only, measured before the GPU is touched): the C oracle (OpenMP,
+every core granted) on a crop, one-thread numpy rows, and the vectorised numpy form
+on every granted core through multiprocessing.
 '''
 import argparse
 import json
@@ -112,17 +114,29 @@ def numpy_rows(seed):
                            f'as the reference evaluates them'})
     ch, cw = WIN + 255, WIN + 1023
     left, right = synthetic_pair(ch, cw, seed)
+    t0 = time.perf_counter()
+    n_eval = numpy_band_scan(left, right)
+    dt = time.perf_counter() - t0
+    rows.append({'value': n_eval / dt, 'unit': 'NCC window evals/s', 'cores': 1, 'kind': 'port',
+                 'sample': f'{ch}x{cw} crop, {n_eval} evaluations in {dt:.2f} s, vectorised numpy '
+                           f'(product image per offset + summed-area tables)'})
+    return rows
+
+
+def numpy_band_scan(left, right):
+    """The band scan's arithmetic in vectorised numpy (one product image per offset, box
+    sums through summed-area tables, running maximum per window); returns the number of
+    (window, offset) evaluations made."""
     lf, rf = left.astype(np.float64) - 128.0, right.astype(np.float64) - 128.0
 
     def box(a):
         sat = np.zeros((a.shape[0] + 1, a.shape[1] + 1))
         np.cumsum(np.cumsum(a, axis=0), axis=1, out=sat[1:, 1:])
         return sat[WIN:, WIN:] - sat[:-WIN, WIN:] - sat[WIN:, :-WIN] + sat[:-WIN, :-WIN]
-    t0 = time.perf_counter()
     n = float(WIN * WIN)
     sl, sr = box(lf), box(rf)
     al, ar = n * box(lf * lf) - sl * sl, n * box(rf * rf) - sr * sr
-    nwx = cw - WIN + 1
+    nwx = left.shape[1] - WIN + 1
     best = np.full(sl.shape, -np.inf)
     n_eval = 0
     with np.errstate(all='ignore'):
@@ -136,11 +150,29 @@ def numpy_rows(seed):
                 np.sqrt(al[:, lo:hi] * ar[:, lo + d:hi + d])
             np.maximum(best[:, lo:hi], score, out=best[:, lo:hi])
             n_eval += score.size
-    dt = time.perf_counter() - t0
-    rows.append({'value': n_eval / dt, 'unit': 'NCC window evals/s', 'cores': 1, 'kind': 'port',
-                 'sample': f'{ch}x{cw} crop, {n_eval} evaluations in {dt:.2f} s, vectorised numpy '
-                           f'(product image per offset + summed-area tables)'})
-    return rows
+    return n_eval
+
+
+def _numpy_band_worker(job):
+    seed, rows = job
+    left, right = synthetic_pair(WIN + rows - 1, WIN + 1023, seed)
+    return numpy_band_scan(left, right)
+
+
+def numpy_all_cores(seed, cores):
+    """The vectorised numpy form on every granted host core: one process per core
+    (multiprocessing, forked before this process touches the GPU), each scanning a band
+    of 96 window rows of a pair of its own."""
+    import multiprocessing as mp
+    rows = 96
+    with mp.get_context('fork').Pool(cores) as pool:
+        pool.map(_numpy_band_worker, [(seed + 7 * i, 8) for i in range(cores)])        # workers up, numpy warm
+        t0 = time.perf_counter()
+        counts = pool.map(_numpy_band_worker, [(seed + i, rows) for i in range(cores)])
+        dt = time.perf_counter() - t0
+    return {'value': sum(counts) / dt, 'unit': 'NCC window evals/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{cores} processes x ({rows} window rows x 1024 windows x {2 * MAX_DISP + 1} offsets), '
+                      f'{sum(counts)} evaluations in {dt:.2f} s, vectorised numpy via multiprocessing'}
 
 
 def cpu_baseline(height, width, seed):
@@ -148,7 +180,7 @@ def cpu_baseline(height, width, seed):
     on a crop of the same synthetic pair; one-thread numpy rows beside it."""
     from oracle import ncc_oracle
     ncc_oracle.build()
-    ch, cw = 31 + 1023, 31 + 1023       # 1024 x 1024 windows
+    ch, cw = 31 + 255, 31 + 1023        # 256 x 1024 windows: a few seconds on 16 cores
     left, right = synthetic_pair(ch, cw, seed)
     cores = ncc_oracle.max_threads()
     t0 = time.perf_counter()
@@ -158,7 +190,8 @@ def cpu_baseline(height, width, seed):
     out = {'value': evals / dt, 'unit': 'NCC window evals/s', 'cores': cores, 'kind': 'port',
            'sample': f'{ch}x{cw} crop of the same synthetic pair, {evals} evals in {dt:.2f} s '
                      f'(oracle/ncc_oracle.c orc_band_scan, OpenMP)',
-           'numpy_one_thread': numpy_rows(seed)}
+           'numpy_one_thread': numpy_rows(seed),
+           'numpy_all_cores': numpy_all_cores(seed, cores)}
     try:
         import numba  # noqa: F401
         out['numba'] = 'importable but not timed: the reference\'s njit kernels are 1D only'
@@ -171,7 +204,7 @@ class Sharded:
     """One rank's share of a scan: a band of window rows of one pair (its image rows
     plus a halo of WIN - 1 rows) with the buffers its results travel in."""
 
-    def __init__(self, bs, torch, left, right, rows, world, rank, wire, wire_windows):
+    def __init__(self, bs, torch, left, right, rows, world, rank, wire, wire_windows, device='cuda'):
         begin, end = rows
         self.rows = rows
         h = end - begin + WIN - 1
@@ -183,10 +216,10 @@ class Sharded:
         # correlations (16-bit integers are not a collective dtype).  Every rank's
         # buffer has the size of the largest share (shares differ by one window row at
         # most): a gather wants equal sizes.
-        self.cap = cap = wire_windows
+        self.cap = cap = wire_windows + (wire_windows & 1)      # the float32 half starts 4-byte aligned
         self.packed, self.disp16, self.val32 = [], [], []
         for _ in range(2 if world > 1 else 0):          # two buffers take turns
-            buf = torch.zeros(6 * cap, dtype=torch.uint8, device='cuda')
+            buf = torch.zeros(6 * cap, dtype=torch.uint8, device=device)
             self.packed.append(buf)
             self.disp16.append(buf[:2 * cap].view(torch.int16)[:self.nwin].view(self.scanner.disp.shape))
             self.val32.append(buf[2 * cap:].view(torch.float32)[:self.nwin].view(self.scanner.val.shape))
@@ -235,30 +268,46 @@ def unpack_results(raw, cap, n):
     return raw[:2 * cap].view(np.int16)[:n].copy(), raw[2 * cap:].view(np.float32)[:n].copy()
 
 
-def timed(torch, dist, world, wire, job, steps, warmup, events=None):
+def timed(torch, dist, world, wire, job, steps, warmup, events=None, sync=None):
     """W untimed steps, then exactly K timed ones between barriers and device
-    synchronisations; the maximum over ranks."""
+    synchronisations; the maximum over ranks.  `sync` replaces
+    torch.cuda.synchronize (the CPU rehearsal of the multi-rank path has no device)."""
+    sync = sync or torch.cuda.synchronize
     for _ in range(warmup):
         job.step(dist)
     job.drain()
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
-        torch.cuda.synchronize()
+        sync()
     t0 = time.perf_counter()
     for i in range(steps):
         job.step(dist, (events[0][i], events[1][i]) if events else None)
     job.drain()
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
-        torch.cuda.synchronize()
+        sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=wire)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     return elapsed
+
+
+def slowest_rank(torch, dist, world, wire, kernel_ms, achieved, evals):
+    """The band kernel's figures on the rank where it ran at the lowest rate: (average
+    launch duration in ms, TFLOP/s, evaluations per launch).  Every rank times its own
+    launches; the roofline entry must not flatter the job with rank 0's device."""
+    if world == 1:
+        return kernel_ms, achieved, evals
+    mine = torch.tensor([kernel_ms, achieved, float(evals)], dtype=torch.float64, device=wire)
+    every = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(every, mine)
+    rows = [t.cpu().tolist() for t in every]
+    worst = min(rows, key=lambda r: r[1])
+    return worst[0], worst[1], int(worst[2])
 
 
 def main():
@@ -272,14 +321,16 @@ def main():
     ap.add_argument('--no-weak', action='store_true', help='skip the secondary weak-scaling measurement')
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
-
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
+    # the CPU rows first: their worker processes are forked before this process holds a GPU context
+    cpu_rows = cpu_baseline(args.height, args.width, seed=1000) if world == 1 and not args.no_cpu_baseline else None
+
+    import torch
+    import torch.distributed as dist
     # SVAMD_BENCH_BACKEND=gloo rehearses the multi-process path on a box with fewer
     # GPUs than ranks (ranks share devices, results travel through host memory)
     backend = os.environ.get('SVAMD_BENCH_BACKEND', 'nccl')
@@ -309,6 +360,8 @@ def main():
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     elapsed = timed(torch, dist, world, wire, job, args.steps, args.warmup, (ev0, ev1))
     kernel_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / args.steps
+    achieved = my_evals * 2.0 * WIN * WIN / (kernel_ms * 1e-3) / 1e12
+    kernel_ms, achieved, slowest_evals = slowest_rank(torch, dist, world, wire, kernel_ms, achieved, my_evals)
 
     # the gathered map against one rank scanning the whole pair alone
     check = None
@@ -339,8 +392,7 @@ def main():
         weak = world * evals * args.steps / wel
 
     if rank == 0:
-        flops_per_launch = my_evals * 2.0 * WIN * WIN
-        achieved = flops_per_launch / (kernel_ms * 1e-3) / 1e12
+        flops_per_launch = slowest_evals * 2.0 * WIN * WIN
         line = {
             'metric': 'NCC window evals/sec (whole node)',
             'value': evals * args.steps / elapsed,
@@ -372,6 +424,7 @@ def main():
                 'unit': 'TFLOP/s',
                 'frac': achieved / FP32_VALU_PEAK_TFLOPS,
                 'kernel_ms': kernel_ms,
+                'kernel_ms_is': 'average launch of the slowest rank',
                 'flops_per_launch': flops_per_launch,
                 'traffic': None,
             },
@@ -385,8 +438,8 @@ def main():
         if traffic and (H, W) == (4096, 4096) and world == 1:
             line['roofline']['traffic'] = traffic['bytes_per_launch']
             line['roofline']['traffic_source'] = traffic['source']
-        if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline(H, W, seed=1000)
+        if cpu_rows is not None:
+            line['cpu_baseline'] = cpu_rows
         print(json.dumps(line), flush=True)
         if check is False:
             raise SystemExit('the gathered disparity map differs from the single-GPU scan')

@@ -130,7 +130,11 @@ int svamd_cross_correlate_1d(const double *v1, const double *v2, int64_t n, int 
  * SVAMD_XCORR1D_STATIC_MAX_N samples (SVAMD_ERR_LIMIT beyond).  All calls on one
  * device share that array: calls that overlap in time on one device (different
  * streams or threads) race; calls on one stream, or on different devices, do
- * not.  Results equal svamd_cross_correlate_1d's bit for bit. */
+ * not.  A non-NULL stream must belong to the current device (SVAMD_ERR_INVALID
+ * otherwise).  The first call on each device looks up the array's address and must
+ * be made outside stream capture; later calls on that device are plain kernel
+ * launches and memsets and can be captured.  Results equal svamd_cross_correlate_1d's
+ * bit for bit. */
 #define SVAMD_XCORR1D_STATIC_MAX_N 65536
 int svamd_cross_correlate_1d_static(const double *v1, const double *v2, int64_t n, int normalised,
                                     double *out, void *stream);

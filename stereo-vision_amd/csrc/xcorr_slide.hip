@@ -947,7 +947,7 @@ spatial_epilogue_kernel(double *__restrict__ out, int orows, int ocols, int sx, 
                         int rh, int rw, int region_dtype, const Stats *__restrict__ tst,
                         const Stats *__restrict__ rst, const double *__restrict__ tsat,
                         const TSat *__restrict__ s1, const TSat *__restrict__ s2,
-                        const double *__restrict__ planes, int nplanes)
+                        const double *__restrict__ planes, int nplanes, const void *__restrict__ region)
 {
     const int64_t total = (int64_t)orows * ocols;
     const int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -970,7 +970,7 @@ spatial_epilogue_kernel(double *__restrict__ out, int orows, int ocols, int sx, 
     const TSat a1 = rect_sum(s1, tp, y0, x0, y0 + h, x0 + w);
     const TSat a2 = rect_sum(s2, tp, y0, x0, y0 + h, x0 + w);
     // integer tables: sums of the pixels; float64 tables: sums of (pixel - c)
-    const double rmean = (double)a1 / n;
+    double rmean = (double)a1 / n;
     double rstd;
     bool flat;
     if constexpr (std::is_integral<TSat>::value) {
@@ -980,18 +980,41 @@ spatial_epilogue_kernel(double *__restrict__ out, int orows, int ocols, int sx, 
         rstd = sqrt((double)var_n2) / n;
     } else {
         const double m2 = (double)a2 / n;
-        const double var = m2 - rmean * rmean;
-        // A constant snapshot must come out as NaN, but its variance is a difference of
-        // rounded table entries: anything below the rounding noise of the four corners
-        // involved (64 units in the last place of the largest of them) counts as zero.
+        double var = m2 - rmean * rmean;
+        // The variance is a difference of rounded table entries whose magnitude follows
+        // the image, not the window: its absolute error is a few units in the last place
+        // of the four corners involved.  A window whose variance is not far above that
+        // (a low-contrast patch of a large image) takes its mean and deviation from its
+        // own pixels instead, two passes, and counts as constant (NaN, the reference's
+        // 0 / 0) only when every pixel has the same value.
         const double c1 = fmax(fmax(fabs((double)s1[(int64_t)y0 * tp + x0]), fabs((double)s1[(int64_t)y0 * tp + x0 + w])),
                                fmax(fabs((double)s1[(int64_t)(y0 + h) * tp + x0]),
                                     fabs((double)s1[(int64_t)(y0 + h) * tp + x0 + w])));
         const double c2 = fmax(fmax(fabs((double)s2[(int64_t)y0 * tp + x0]), fabs((double)s2[(int64_t)y0 * tp + x0 + w])),
                                fmax(fabs((double)s2[(int64_t)(y0 + h) * tp + x0]),
                                     fabs((double)s2[(int64_t)(y0 + h) * tp + x0 + w])));
-        const double noise = 64.0 * 2.220446049250313e-16 * (c2 + 2.0 * fabs(rmean) * c1) / n;
-        flat = !(var > noise);
+        const double ulp = 2.220446049250313e-16 * (c2 + 2.0 * fabs(rmean) * c1) / n;
+        flat = false;
+        if (!(var > 1e7 * ulp)) {
+            const double centre = rst->mean;            // what the tables' pixels were centred by
+            double sum = 0.0, lo = INFINITY, hi = -INFINITY;
+            for (int y = 0; y < h; ++y)
+                for (int x = 0; x < w; ++x) {
+                    const double p = load_as_double(region, region_dtype, (int64_t)(y0 + y) * rw + x0 + x);
+                    sum += p - centre;
+                    lo = fmin(lo, p);
+                    hi = fmax(hi, p);
+                }
+            rmean = sum / n;
+            double dev = 0.0;
+            for (int y = 0; y < h; ++y)
+                for (int x = 0; x < w; ++x) {
+                    const double d = load_as_double(region, region_dtype, (int64_t)(y0 + y) * rw + x0 + x) - centre - rmean;
+                    dev += d * d;
+                }
+            var = dev / n;
+            flat = lo == hi;
+        }
         rstd = sqrt(var);
     }
     const double tstd = tst->std;
@@ -1197,11 +1220,13 @@ extern "C" int svamd_cross_correlate_2d(const double *tmpl, int th, int tw, cons
     if (region_dtype == SVAMD_U8)
         hipLaunchKernelGGL((spatial_epilogue_kernel<int64_t>), eg, dim3(256), 0, st, out, orows, ocols,
                            step_x, step_y, th, tw, rh, rw, region_dtype, tst, rst, tsat,
-                           static_cast<const int64_t *>(s1), static_cast<const int64_t *>(s2), partial, nplanes);
+                           static_cast<const int64_t *>(s1), static_cast<const int64_t *>(s2), partial, nplanes,
+                           region);
     else
         hipLaunchKernelGGL((spatial_epilogue_kernel<double>), eg, dim3(256), 0, st, out, orows, ocols,
                            step_x, step_y, th, tw, rh, rw, region_dtype, tst, rst, tsat,
-                           static_cast<const double *>(s1), static_cast<const double *>(s2), partial, nplanes);
+                           static_cast<const double *>(s1), static_cast<const double *>(s2), partial, nplanes,
+                           region);
     SV_LAUNCH_CHECK();
     return SVAMD_OK;
 }
@@ -1515,10 +1540,28 @@ extern "C" int svamd_cross_correlate_1d_static(const double *v1, const double *v
     int dev = -1;
     SV_HIP(hipGetDevice(&dev));
     SV_REQUIRE(dev >= 0 && dev < MAX_DEVICES, SVAMD_ERR_LIMIT, "cross_correlate_1d_static: device index %d", dev);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (st) {
+        // The array is looked up on the current device; kernels of a stream that lives on
+        // another device would be handed an address that means nothing there.
+        int stream_dev = -1;
+        SV_HIP(hipStreamGetDevice(st, &stream_dev));
+        SV_REQUIRE(stream_dev == dev, SVAMD_ERR_INVALID,
+                   "cross_correlate_1d_static: the stream belongs to device %d but device %d is current; make the "
+                   "stream's device current before the call", stream_dev, dev);
+    }
     void *ws;
     {
         std::lock_guard<std::mutex> lock(scratch_mutex);
         if (!scratch_ptr[dev]) {
+            // First call on this device.  Looking the address up is not a stream operation:
+            // keep it out of a graph capture (one plain call per device comes first).
+            hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+            if (st)
+                SV_HIP(hipStreamIsCapturing(st, &capturing));
+            SV_REQUIRE(capturing == hipStreamCaptureStatusNone, SVAMD_ERR_INVALID,
+                       "cross_correlate_1d_static: the first call on a device must be made outside stream "
+                       "capture (it looks up the built-in workspace's address)");
             void *p = nullptr;
             SV_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(xcorr1d_scratch)));
             SV_REQUIRE(p && (reinterpret_cast<uintptr_t>(p) & 255) == 0, SVAMD_ERR_HIP,

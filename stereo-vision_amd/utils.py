@@ -38,7 +38,9 @@ def resident_float64(image):
     '''float64 device copy of a host image: the twin a ResidentImage carries, or
     a fresh upload.'''
     twin = getattr(image, 'resident', None)
-    if twin is not None and tuple(twin.shape) == tuple(np.shape(image)):
+    # a twin is trusted only while the host array cannot have been edited: numpy lets a
+    # caller flip `image.flags.writeable` without going through setflags()
+    if twin is not None and not image.flags.writeable and tuple(twin.shape) == tuple(np.shape(image)):
         return twin
     return nv.to_device(np.ascontiguousarray(image, dtype=np.float64))
 
@@ -121,7 +123,7 @@ def downsample(image, factor=1):
     height, width = image.shape
     out_h, out_w = math.floor(height / factor), math.floor(width / factor)
     twin = getattr(image, 'resident', None)
-    if twin is not None and tuple(twin.shape) == (height, width):
+    if twin is not None and not image.flags.writeable and tuple(twin.shape) == (height, width):
         d_in, code = twin, nv.F64
     else:
         host = np.asarray(image)

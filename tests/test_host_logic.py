@@ -187,6 +187,22 @@ def test_resident_image_is_a_read_only_array_with_a_twin():
     assert image.resident is None
     image[0, 0] = 5.0
     assert image[0, 0] == 5.0
+    # the flag flipped directly (numpy does not route that through setflags): the twin is
+    # still attached but no longer used, the edited pixels are uploaded
+    uploads = []
+    import types
+    twin = types.SimpleNamespace(shape=(3, 4))
+    image = utils.ResidentImage(np.arange(12.0).reshape(3, 4), twin)
+    assert utils.resident_float64(image) is twin
+    image.flags.writeable = True
+    image[0, 0] = 7.0
+    import _native as nv
+    real = nv.to_device
+    nv.to_device = lambda a: uploads.append(np.array(a)) or 'uploaded'
+    try:
+        assert utils.resident_float64(image) == 'uploaded' and uploads[0][0, 0] == 7.0
+    finally:
+        nv.to_device = real
 
 
 def test_band_scan_input_levels():

@@ -153,6 +153,31 @@ def test_spatial_float_region_with_large_mean(mods, oracle):
     assert np.unravel_index(np.argmax(got), got.shape) == (20, 20)
 
 
+def test_spatial_low_contrast_patch_of_a_large_float_region(mods, oracle):
+    '''A patch whose deviation is 1e-5 of the image's, far from the origin of a 2048 x
+    2048 float region: the variance of a window inside it is below the rounding of the
+    summed-area tables there, so it comes from the window's own pixels - finite values
+    that match the oracle, not NaN.  An exactly constant patch is NaN (the reference's
+    0 / 0).'''
+    rng = np.random.default_rng(31)
+    region = rng.random((2048, 2048))
+    region[1800:1864, 1900:1964] = 0.5 + 1e-5 * region.std() * rng.standard_normal((64, 64))
+    region[600:640, 200:240] = 0.25
+    template = rng.random((16, 16))
+    got = quiet(mods['c'].cross_correlate_2d, template, region, 8, 8)
+    want = oracle.cross_correlate_2d(template, region, 8, 8)
+    inside = (slice(1800 // 8, (1864 - 16) // 8 + 1), slice(1904 // 8, (1964 - 16) // 8 + 1))
+    assert np.isfinite(want[inside]).all() and np.isfinite(got[inside]).all()
+    assert np.abs(want[inside]).max() > 0.05
+    constant = (slice(600 // 8, (640 - 16) // 8 + 1), slice(200 // 8, (240 - 16) // 8 + 1))
+    assert np.isnan(got[constant]).all()
+    # the reference's own value for a constant float snapshot is rounding noise over
+    # rounding noise (its mean of equal numbers need not equal them): left out of the comparison
+    keep = np.ones(got.shape, dtype=bool)
+    keep[constant] = False
+    assert_surface_close(np.where(keep, got, 0.0), np.where(keep, want, 0.0), SURFACE_TOL, 'low-contrast patch')
+
+
 def test_spatial_random_shapes_and_steps_vs_oracle(mods, oracle):
     '''Random template / region shapes (1 x 1 up to 300 x 700) and steps 1..8 in each
     direction, uint8 regions with and without a NaN-masked template and float regions:

@@ -8,6 +8,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch.multiprocessing as mp
 
 import helpers  # noqa: F401
@@ -137,3 +138,72 @@ def test_band_rows_with_halo_gathered_equal_whole_scan(tmp_path, oracle):
     total = bench.count_evals(left.shape[0], left.shape[1], 15, 6)
     assert sum(bench.count_evals(left.shape[0], left.shape[1], 15, 6, rows=e - b)
                for b, e in [(0, nwy // 2), (nwy // 2, nwy)]) == total
+
+
+class OracleBandScanner:
+    '''band_scan.BandScanner's interface on the CPU, the oracle doing the scan: what
+    bench.Sharded needs from a scanner (upload, prepare, run, disp, val).'''
+
+    def __init__(self, height, width, win_w, win_h, max_disp):
+        import torch
+        self.win, self.max_disp = win_w, max_disp
+        self.disp = torch.zeros((height - win_h + 1, width - win_w + 1), dtype=torch.int32)
+        self.val = torch.zeros((height - win_h + 1, width - win_w + 1), dtype=torch.float64)
+
+    def upload(self, left, right):
+        self.left, self.right = np.ascontiguousarray(left), np.ascontiguousarray(right)
+
+    def prepare(self):
+        pass
+
+    def run(self, threshold, prepared=False):
+        import torch
+        from oracle import ncc_oracle
+        disp, val = ncc_oracle.band_scan(self.left, self.right, self.win, self.win, self.max_disp, mode='fold',
+                                         threshold=threshold)
+        self.disp.copy_(torch.from_numpy(disp))
+        self.val.copy_(torch.from_numpy(val))
+
+
+def bench_worker(rank, size, port, out_dir):
+    '''bench.py's own step loop (Sharded.step with its two wire buffers taking turns and
+    the asynchronous gather, drain, timed's barriers and max-over-ranks, last_gathered,
+    slowest_rank) over gloo, the oracle standing in for the band kernel.'''
+    import types
+    import torch
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=size)
+    try:
+        import bench
+        import sharding
+        bench.WIN, bench.MAX_DISP = 15, 6
+        left, right = band_pair()
+        nwy, nwx = left.shape[0] - 15 + 1, left.shape[1] - 15 + 1
+        bands = [sharding.shard_range(nwy, r, size) for r in range(size)]
+        counts = [(e - b) * nwx for b, e in bands]
+        job = bench.Sharded(types.SimpleNamespace(BandScanner=OracleBandScanner), torch, left, right, bands[rank],
+                            size, rank, 'cpu', max(counts), device='cpu')
+        elapsed = bench.timed(torch, dist, size, 'cpu', job, steps=3, warmup=1, sync=lambda: None)
+        assert elapsed > 0 and job.issued == 4 and job.in_flight == [None, None]
+        worst = bench.slowest_rank(torch, dist, size, 'cpu', 10.0 + rank, 5.0 - rank, 100 + rank)
+        assert worst == (10.0 + size - 1, 5.0 - (size - 1), 100 + size - 1)
+        if rank == 0:
+            parts = job.last_gathered(counts)
+            np.save(os.path.join(out_dir, 'disp.npy'), np.concatenate([d for d, _ in parts]).reshape(nwy, nwx))
+            np.save(os.path.join(out_dir, 'val.npy'), np.concatenate([v for _, v in parts]).reshape(nwy, nwx))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('size', [2, 3])
+def test_bench_step_loop_gathers_the_whole_map(tmp_path, oracle, size):
+    '''37 window rows over 2 and over 3 ranks (uneven shares): after bench.py's timed loop
+    the last gathered map equals one process scanning the whole pair, bit for bit.'''
+    mp.spawn(bench_worker, args=(size, free_port(), str(tmp_path)), nprocs=size, join=True)
+    left, right = band_pair()
+    assert (left.shape[0] - 15 + 1) % size != 0
+    disp, val = oracle.band_scan(left, right, 15, 15, 6, mode='fold', threshold=0.5)
+    assert np.array_equal(np.load(tmp_path / 'disp.npy'), disp.astype(np.int16))
+    assert np.array_equal(np.load(tmp_path / 'val.npy'), val.astype(np.float32))
