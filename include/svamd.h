@@ -254,6 +254,29 @@ int svamd_band_scan_u8(const uint8_t *left, const uint8_t *right, int H, int W,
                        int32_t *out_disp, double *out_val, double *scores,
                        void *workspace, size_t workspace_bytes, void *stream);
 
+/* The dense band scan for float64 images (what utils.downsample, utils.py:28-35, returns
+ * for factors above 1, where pixels are no longer 8-bit levels).  Same windows, offsets,
+ * modes and outputs as svamd_band_scan_u8.  The cross terms are accumulated in float32
+ * from pixels centred so that the products are products of deviations (scores within
+ * about 1e-6 of a float64 evaluation); every window whose closest decision came within
+ * guard_band of going the other way is then evaluated again in float64, all offsets,
+ * and its result replaced, so the selected offsets are those of a float64 evaluation
+ * (guard_band 0 skips that).  Window statistics come from float64 summed-area tables of
+ * the centred pixels; windows too flat for the tables' rounding take them from their own
+ * pixels, and exactly constant windows give NaN scores (the reference's 0 / 0).
+ * Images with NaN pixels are not supported.  Limits: win_w * win_h <= 4096,
+ * stride_x == 1, the LDS tile as above.  Widths 25 and 31 have unrolled kernels. */
+size_t svamd_band_scan_f64_workspace_bytes(int H, int W, int win_w, int win_h);
+int svamd_band_prepare_f64(const double *left, const double *right, int H, int W,
+                           int win_w, int win_h, void *workspace, size_t workspace_bytes,
+                           void *stream);
+int svamd_band_scan_f64(const double *left, const double *right, int H, int W,
+                        int win_w, int win_h, int stride_x, int stride_y, int max_disp,
+                        int mode, double threshold, double centre_tol, double guard_band,
+                        int row_begin, int row_end, int flags,
+                        int32_t *out_disp, double *out_val, double *scores,
+                        void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- displacement grids: the accumulation after a scan ---------------------------
  * test_image_comparison.py:61-92.  Every window of a sequence paints dp_x, dp_y,
  * |dp| and (if |dp| > 0) a count of 1 over its box of four H x W float64 grids;

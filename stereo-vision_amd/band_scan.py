@@ -6,7 +6,11 @@ pixel and a band of candidate offsets on the same image rows - libsvamd
 evaluates all of it in one kernel (svamd_band_scan_u8): the spatial NCC of
 reference correlation.py:104-116 at full overlap, then per window either the
 arg-max of utils.max_pos (utils.py:17-26) or image_scan's selection rule
-(sv_image_comparison.py:249-255).
+(sv_image_comparison.py:249-255).  8-bit images (uint8, or 8-bit levels scaled
+to 0..1) take the integer-exact kernel; any other floating-point image - what
+the reference's downsample() returns for factors above 1 - takes
+svamd_band_scan_f64 (float32 products of centred pixels, every near-tie
+re-evaluated in float64).
 '''
 import numpy as np
 
@@ -31,17 +35,24 @@ def as_uint8_image(image):
         if q.min() >= 0 and q.max() <= 255 and (np.array_equal(q / 255.0, image) or
                                                  np.array_equal(q * (1.0 / 255), image)):
             return np.ascontiguousarray(q.astype(np.uint8))
-    raise TypeError('band_scan needs 8-bit images (uint8, or uint8 / 255 as float)')
+    raise TypeError('not an 8-bit image (uint8, or uint8 / 255 as float)')
+
+
+def _as_float_image(image):
+    image = np.asarray(image)
+    if image.dtype.kind not in 'fiub':
+        raise TypeError(f'band_scan needs real-valued images, got {image.dtype}')
+    return np.ascontiguousarray(image, dtype=np.float64)
 
 
 class BandScanner:
     '''Device-resident state for repeated scans of same-sized pairs: images,
-    workspace and outputs are allocated once.'''
+    workspace and outputs are allocated once (per pixel type: a scanner that
+    is handed floating-point images after 8-bit ones holds both sets).'''
 
     def __init__(self, height, width, window_width, window_height, max_disparity, row_stride=1,
                  want_scores=False):
         torch = nv.torch_cuda()
-        lib = nv.load_library()
         self.shape = (height, width)
         self.win = (window_width, window_height)
         self.max_disp = int(max_disparity)
@@ -50,26 +61,43 @@ class BandScanner:
         self.nwy = (height - window_height) // self.row_stride + 1
         if self.nwx <= 0 or self.nwy <= 0:
             raise Exception('Dimensions of template must not exceed those of region.')
-        nbytes = lib.svamd_band_scan_u8_workspace_bytes(height, width, window_width, window_height)
-        self.ws = nv.workspace(nbytes)
-        self.left = nv.empty((height, width), torch.uint8)
-        self.right = nv.empty((height, width), torch.uint8)
+        self.kind = 'u8'
+        self._sets = {}
+        self._buffers('u8')
         self.disp = nv.empty((self.nwy, self.nwx), torch.int32)
         self.val = nv.empty((self.nwy, self.nwx), torch.float64)
         self.scores = (nv.empty((self.nwy, self.nwx, 2 * self.max_disp + 1), torch.float64)
                        if want_scores else None)
 
+    def _buffers(self, kind):
+        '''(left, right, workspace) on the device for 'u8' or 'f64' pixels.'''
+        if kind not in self._sets:
+            torch = nv.torch_cuda()
+            lib = nv.load_library()
+            sizer = lib.svamd_band_scan_u8_workspace_bytes if kind == 'u8' else lib.svamd_band_scan_f64_workspace_bytes
+            dtype = torch.uint8 if kind == 'u8' else torch.float64
+            self._sets[kind] = (nv.empty(self.shape, dtype), nv.empty(self.shape, dtype),
+                                nv.workspace(sizer(*self.shape, *self.win)))
+        self.left, self.right, self.ws = self._sets[kind]
+        self.kind = kind
+
     def upload(self, left, right):
         torch = nv.torch_cuda()
-        self.left.copy_(torch.from_numpy(as_uint8_image(left)))
-        self.right.copy_(torch.from_numpy(as_uint8_image(right)))
+        try:
+            left, right, kind = as_uint8_image(left), as_uint8_image(right), 'u8'
+        except TypeError:
+            left, right, kind = _as_float_image(left), _as_float_image(right), 'f64'
+        self._buffers(kind)
+        self.left.copy_(torch.from_numpy(left))
+        self.right.copy_(torch.from_numpy(right))
 
     def prepare(self):
         '''Enqueues the summed-area tables / window statistics of the uploaded
         pair (kernel K1); run(prepared=True) then skips them.'''
         h, w = self.shape
-        nv.call('svamd_band_prepare_u8', nv.ptr(self.left), nv.ptr(self.right), h, w,
-                self.win[0], self.win[1], nv.ptr(self.ws), self.ws.numel(), nv.stream_ptr())
+        nv.call('svamd_band_prepare_u8' if self.kind == 'u8' else 'svamd_band_prepare_f64', nv.ptr(self.left),
+                nv.ptr(self.right), h, w, self.win[0], self.win[1], nv.ptr(self.ws), self.ws.numel(),
+                nv.stream_ptr())
 
     def run(self, correlation_threshold=None, rows=None, prepared=False):
         '''Enqueues one scan on the current stream.  correlation_threshold None:
@@ -78,12 +106,16 @@ class BandScanner:
         h, w = self.shape
         mode = nv.BAND_ARGMAX if correlation_threshold is None else nv.BAND_FOLD
         begin, end = rows if rows is not None else (0, self.nwy)
-        nv.call('svamd_band_scan_u8', nv.ptr(self.left), nv.ptr(self.right), h, w,
-                self.win[0], self.win[1], 1, self.row_stride, self.max_disp, mode,
-                float(correlation_threshold or 0.0), float(_svic.CENTRE_TOL), int(begin), int(end),
-                nv.BAND_PREPARED if prepared else 0,
-                nv.ptr(self.disp), nv.ptr(self.val), nv.ptr(self.scores),
-                nv.ptr(self.ws), self.ws.numel(), nv.stream_ptr())
+        head = (nv.ptr(self.left), nv.ptr(self.right), h, w, self.win[0], self.win[1], 1, self.row_stride,
+                self.max_disp, mode, float(correlation_threshold or 0.0), float(_svic.CENTRE_TOL))
+        tail = (int(begin), int(end), nv.BAND_PREPARED if prepared else 0, nv.ptr(self.disp), nv.ptr(self.val),
+                nv.ptr(self.scores), nv.ptr(self.ws), self.ws.numel(), nv.stream_ptr())
+        if self.kind == 'u8':
+            nv.call('svamd_band_scan_u8', *head, *tail)
+        else:
+            # float32 products; decisions within the scan's guard band are repeated in float64
+            guard = 0.0 if _svic.SCAN_PRECISION == 'fp32' else float(_svic.GUARD_BAND)
+            nv.call('svamd_band_scan_f64', *head, guard, *tail)
 
 
 def band_scan(left_image, right_image, window_width, window_height, max_disparity,
@@ -93,8 +125,7 @@ def band_scan(left_image, right_image, window_width, window_height, max_disparit
     Returns (disparity int32 [rows, cols], correlation float64 [rows, cols]) and,
     if asked, the full score volume [rows, cols, 2*max_disparity+1] (NaN where a
     candidate box leaves the image or a window is constant).'''
-    left = as_uint8_image(left_image)
-    right = as_uint8_image(right_image)
+    left, right = np.asarray(left_image), np.asarray(right_image)
     if left.shape != right.shape:
         raise Exception('Dimensions of template and region images must match')
     scanner = BandScanner(left.shape[0], left.shape[1], window_width, window_height, max_disparity,

@@ -22,6 +22,16 @@
 // loop is bound by the vector ALU, not by LDS.  Offsets are visited in ascending
 // order inside a lane, so the sequential selection rule needs no cross-lane
 // traffic at all; only the final results are written.
+//
+// Floating-point images (what the reference's downsample() produces for factors
+// above 1) run through the same kernel with PIX = double: pixels are staged as
+// float32 after the image mean is taken off, every lane additionally takes a constant
+// of its own off the values it reads (about the mean of its windows / of the boxes
+// of the pass), so that the float32 products it adds up are products of deviations,
+// and the epilogue puts those constants back in float64.  Window sums come from
+// float64 tables.  Each window records how close its closest decision came to
+// flipping; windows within the caller's guard band are evaluated again in float64
+// (band_recheck_kernel), so the selected offsets are those of a float64 evaluation.
 #include <type_traits>
 #include <utility>
 
@@ -73,9 +83,11 @@ window_stats_kernel(const uint32_t *__restrict__ s1, const uint32_t *__restrict_
 }
 
 // ---- LDS tile staging ---------------------------------------------------------------
-// dst[r][c] = img[row0 + r][col0 + c] - 128 as float32, 0 outside the image.
-__device__ __forceinline__ void stage_tile(const uint8_t *__restrict__ img, int H, int W, int row0,
-                                           int nrows, int col0, int pitch, float *__restrict__ dst)
+// dst[r][c] = img[row0 + r][col0 + c] - centre as float32, 0 outside the image
+// (centre = 128 for 8-bit pixels).
+template <typename PIX>
+__device__ __forceinline__ void stage_tile(const PIX *__restrict__ img, int H, int W, int row0,
+                                           int nrows, int col0, int pitch, float *__restrict__ dst, double centre)
 {
     const int quads = pitch / 4;
     for (int i = threadIdx.x; i < nrows * quads; i += BAND_THREADS) {
@@ -83,11 +95,18 @@ __device__ __forceinline__ void stage_tile(const uint8_t *__restrict__ img, int 
         const int y = row0 + r, x = col0 + 4 * q;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (y >= 0 && y < H) {
-            const uint8_t *src = img + (int64_t)y * W;
-            if (x >= 0 && x + 0 < W) v.x = (float)src[x + 0] - 128.f;
-            if (x + 1 >= 0 && x + 1 < W) v.y = (float)src[x + 1] - 128.f;
-            if (x + 2 >= 0 && x + 2 < W) v.z = (float)src[x + 2] - 128.f;
-            if (x + 3 >= 0 && x + 3 < W) v.w = (float)src[x + 3] - 128.f;
+            const PIX *src = img + (int64_t)y * W;
+            if constexpr (std::is_same<PIX, uint8_t>::value) {
+                if (x >= 0 && x + 0 < W) v.x = (float)src[x + 0] - 128.f;
+                if (x + 1 >= 0 && x + 1 < W) v.y = (float)src[x + 1] - 128.f;
+                if (x + 2 >= 0 && x + 2 < W) v.z = (float)src[x + 2] - 128.f;
+                if (x + 3 >= 0 && x + 3 < W) v.w = (float)src[x + 3] - 128.f;
+            } else {
+                if (x >= 0 && x + 0 < W) v.x = (float)(src[x + 0] - centre);
+                if (x + 1 >= 0 && x + 1 < W) v.y = (float)(src[x + 1] - centre);
+                if (x + 2 >= 0 && x + 2 < W) v.z = (float)(src[x + 2] - centre);
+                if (x + 3 >= 0 && x + 3 < W) v.w = (float)(src[x + 3] - centre);
+            }
         }
         *reinterpret_cast<float4 *>(dst + r * pitch + 4 * q) = v;
     }
@@ -129,6 +148,32 @@ __device__ __forceinline__ Quad load_quad(const float *src)
         q.hi = float2v{src[2], src[3]};
     }
     return q;
+}
+
+// Floating-point images: the constants a lane takes off the left / right values it
+// reads (FLT = false: 8-bit images, nothing is taken off and nothing is stored).
+template <bool FLT>
+struct LaneCentre {
+};
+template <>
+struct LaneCentre<true> {
+    float2v a, b;
+};
+template <bool FLT>
+__device__ __forceinline__ void centre_left(Quad &q, const LaneCentre<FLT> &c)
+{
+    if constexpr (FLT) {
+        q.lo -= c.a;
+        q.hi -= c.a;
+    }
+}
+template <bool FLT>
+__device__ __forceinline__ void centre_right(Quad &q, const LaneCentre<FLT> &c)
+{
+    if constexpr (FLT) {
+        q.lo -= c.b;
+        q.hi -= c.b;
+    }
 }
 
 template <int K>
@@ -178,9 +223,9 @@ __device__ __forceinline__ void quad_step(float2v (&acc)[BAND_X / 2][D], const Q
     }
 }
 
-template <int WIN_W, int D, bool ALIGNED, int C = 0>
+template <int WIN_W, int D, bool ALIGNED, bool FLT, int C = 0>
 __device__ __forceinline__ void row_step(float2v (&acc)[BAND_X / 2][D], const float *lp, const float *rp,
-                                         const Quad &l_head, Quad *rq)
+                                         const Quad &l_head, Quad *rq, const LaneCentre<FLT> &lc)
 {
     constexpr int NU = WIN_W + BAND_X - 1;       // left columns touched by the lane's windows
     constexpr int NCL = (NU + 3) / 4;            // ... in groups of four
@@ -188,17 +233,25 @@ __device__ __forceinline__ void row_step(float2v (&acc)[BAND_X / 2][D], const fl
     constexpr int AHEAD = (D + 2) / 4;           // right groups needed beyond group C
     if constexpr (C < NCL) {
         Quad lq;
-        if constexpr (C == 0)
+        if constexpr (C == 0) {
             lq = l_head;                         // prefetched during the previous row
-        else
+            constexpr int HEAD = AHEAD == 0 ? 1 : AHEAD;
+#pragma unroll
+            for (int c = 0; c < HEAD; ++c)       // ... as were the first right quads
+                centre_right<FLT>(rq[c], lc);
+        } else {
             lq = load_quad<true>(lp + 4 * C);
-        if constexpr (C + AHEAD < NCR && C + AHEAD >= AHEAD + (AHEAD == 0 ? 1 : 0))
+        }
+        centre_left<FLT>(lq, lc);
+        if constexpr (C + AHEAD < NCR && C + AHEAD >= AHEAD + (AHEAD == 0 ? 1 : 0)) {
             rq[C + AHEAD] = load_quad<ALIGNED>(rp + 4 * (C + AHEAD));
+            centre_right<FLT>(rq[C + AHEAD], lc);
+        }
         quad_step<WIN_W, D, C>(acc, lq, rq);
         // keeps the scheduler from hoisting the LDS reads of later groups over this one:
         // with them in flight early the row needs more registers than there are (spills)
         __builtin_amdgcn_sched_barrier(0);
-        row_step<WIN_W, D, ALIGNED, C + 1>(acc, lp, rp, l_head, rq);
+        row_step<WIN_W, D, ALIGNED, FLT, C + 1>(acc, lp, rp, l_head, rq, lc);
     }
 }
 
@@ -211,10 +264,10 @@ __device__ __forceinline__ void row_step(float2v (&acc)[BAND_X / 2][D], const fl
 // v_pk_fma_f32 with both multiplicands broadcast, which lets a single wavefront
 // keep its SIMD's FMA pipe full; the outer columns use scalar FMAs.  The first
 // LDS reads of each row are issued during the previous row's arithmetic.
-template <int WIN_W, int D, bool ALIGNED>
+template <int WIN_W, int D, bool ALIGNED, bool FLT>
 __device__ __forceinline__ void accumulate(const float *__restrict__ lp, const float *__restrict__ rp,
                                            int lpitch, int rpitch, int rows,
-                                           float2v (&acc)[BAND_X / 2][D])
+                                           float2v (&acc)[BAND_X / 2][D], const LaneCentre<FLT> &lc)
 {
     constexpr int NU = WIN_W + BAND_X - 1;
     constexpr int NCR = (NU + D - 1 + 3) / 4;
@@ -236,7 +289,7 @@ __device__ __forceinline__ void accumulate(const float *__restrict__ lp, const f
 #pragma unroll
         for (int c = 0; c < HEAD; ++c)
             rqB[c] = load_quad<ALIGNED>(rp + rpitch + 4 * c);
-        row_step<WIN_W, D, ALIGNED>(acc, lp, rp, lA, rqA);
+        row_step<WIN_W, D, ALIGNED, FLT>(acc, lp, rp, lA, rqA, lc);
         lp += lpitch;
         rp += rpitch;
         const float *lnext = a + 2 < rows ? lp + lpitch : lp;
@@ -245,12 +298,12 @@ __device__ __forceinline__ void accumulate(const float *__restrict__ lp, const f
 #pragma unroll
         for (int c = 0; c < HEAD; ++c)
             rqA[c] = load_quad<ALIGNED>(rnext + 4 * c);
-        row_step<WIN_W, D, ALIGNED>(acc, lp, rp, lB, rqB);
+        row_step<WIN_W, D, ALIGNED, FLT>(acc, lp, rp, lB, rqB, lc);
         lp = lnext;
         rp = rnext;
     }
     if (a < rows)
-        row_step<WIN_W, D, ALIGNED>(acc, lp, rp, lA, rqA);
+        row_step<WIN_W, D, ALIGNED, FLT>(acc, lp, rp, lA, rqA, lc);
 }
 
 // acc.x += l.x * r; acc.y += l.y * r with r = half RH of rpair: the left operand
@@ -327,11 +380,21 @@ __device__ __forceinline__ void quad_any(float2v (&acc)[BAND_X / 2][D], const Qu
 // accumulate() for a window width known only at run time (any width the tile
 // geometry admits): the same register tile, the row walked in groups of four
 // columns with the three right quads a group needs rotating through registers.
-template <int D, bool ALIGNED>
+template <int D, bool ALIGNED, bool FLT>
 __device__ __forceinline__ void accumulate_any(const float *__restrict__ lp, const float *__restrict__ rp,
                                                int lpitch, int rpitch, int rows, int win_w,
-                                               float2v (&acc)[BAND_X / 2][D])
+                                               float2v (&acc)[BAND_X / 2][D], const LaneCentre<FLT> &lc)
 {
+    auto left = [&](const float *src) {
+        Quad q = load_quad<true>(src);
+        centre_left<FLT>(q, lc);
+        return q;
+    };
+    auto right = [&](const float *src) {
+        Quad q = load_quad<ALIGNED>(src);
+        centre_right<FLT>(q, lc);
+        return q;
+    };
     static_assert(D <= 9, "three right quads cover offsets 0..8 only");
     const int groups = (win_w + BAND_X - 1 + 3) / 4;
     // groups c = 1 .. last_interior lie inside all four windows (3 <= 4c, 4c + 3 <= win_w - 1)
@@ -343,22 +406,22 @@ __device__ __forceinline__ void accumulate_any(const float *__restrict__ lp, con
     const int rotations = last_interior / 3;
 #pragma unroll 1
     for (int a = 0; a < rows; ++a) {
-        Quad r0 = load_quad<ALIGNED>(rp), r1 = load_quad<ALIGNED>(rp + 4), r2 = load_quad<ALIGNED>(rp + 8);
-        quad_any<D, false>(acc, load_quad<true>(lp), r0, r1, r2, 0, win_w);
+        Quad r0 = right(rp), r1 = right(rp + 4), r2 = right(rp + 8);
+        quad_any<D, false>(acc, left(lp), r0, r1, r2, 0, win_w);
         r0 = r1;
         r1 = r2;
         int c = 1;
         for (int t = 0; t < rotations; ++t, c += 3) {
-            r2 = load_quad<ALIGNED>(rp + 4 * (c + 2));
-            quad_any<D, true>(acc, load_quad<true>(lp + 4 * c), r0, r1, r2, 4 * c, win_w);
-            r0 = load_quad<ALIGNED>(rp + 4 * (c + 3));
-            quad_any<D, true>(acc, load_quad<true>(lp + 4 * c + 4), r1, r2, r0, 4 * c + 4, win_w);
-            r1 = load_quad<ALIGNED>(rp + 4 * (c + 4));
-            quad_any<D, true>(acc, load_quad<true>(lp + 4 * c + 8), r2, r0, r1, 4 * c + 8, win_w);
+            r2 = right(rp + 4 * (c + 2));
+            quad_any<D, true>(acc, left(lp + 4 * c), r0, r1, r2, 4 * c, win_w);
+            r0 = right(rp + 4 * (c + 3));
+            quad_any<D, true>(acc, left(lp + 4 * c + 4), r1, r2, r0, 4 * c + 4, win_w);
+            r1 = right(rp + 4 * (c + 4));
+            quad_any<D, true>(acc, left(lp + 4 * c + 8), r2, r0, r1, 4 * c + 8, win_w);
         }
         for (; c < groups; ++c) {
-            r2 = load_quad<ALIGNED>(rp + 4 * (c + 2));
-            quad_any<D, false>(acc, load_quad<true>(lp + 4 * c), r0, r1, r2, 4 * c, win_w);
+            r2 = right(rp + 4 * (c + 2));
+            quad_any<D, false>(acc, left(lp + 4 * c), r0, r1, r2, 4 * c, win_w);
             r0 = r1;
             r1 = r2;
         }
@@ -369,15 +432,15 @@ __device__ __forceinline__ void accumulate_any(const float *__restrict__ lp, con
 
 // WIN_W > 0: the width is a compile-time constant (fully unrolled row); WIN_W == 0:
 // the width comes from the geometry at run time.
-template <int WIN_W, int D, bool ALIGNED>
+template <int WIN_W, int D, bool ALIGNED, bool FLT>
 __device__ __forceinline__ void accumulate_rows(const float *__restrict__ lp, const float *__restrict__ rp,
                                                 int lpitch, int rpitch, int rows, int win_w,
-                                                float2v (&acc)[BAND_X / 2][D])
+                                                float2v (&acc)[BAND_X / 2][D], const LaneCentre<FLT> &lc)
 {
     if constexpr (WIN_W > 0)
-        accumulate<WIN_W, D, ALIGNED>(lp, rp, lpitch, rpitch, rows, acc);
+        accumulate<WIN_W, D, ALIGNED, FLT>(lp, rp, lpitch, rpitch, rows, acc, lc);
     else
-        accumulate_any<D, ALIGNED>(lp, rp, lpitch, rpitch, rows, win_w, acc);
+        accumulate_any<D, ALIGNED, FLT>(lp, rp, lpitch, rpitch, rows, win_w, acc, lc);
 }
 
 struct LaneState {
@@ -389,21 +452,22 @@ struct LaneState {
 // window into scores and feeds the selection.  k0: offset index (0 .. nd-1) of
 // acc[.][0]; centre_pass: this pass evaluates the centre offset ahead of the
 // ascending sweep (selection-rule mode only).
-template <int D, int D0, int DN>
+template <int D, int D0, int DN, bool FLT, typename TSum>
 __device__ __forceinline__ void finish_range(const BandGeom &g, const float2v (&acc)[BAND_X / 2][D], int k0,
                                              int kend, bool centre_pass, int wy, int xbase,
-                                             const int32_t *__restrict__ wsum_l,
+                                             const TSum *__restrict__ wsum_l,
                                              const double *__restrict__ winv_l,
-                                             const int32_t *__restrict__ wsum_r,
+                                             const TSum *__restrict__ wsum_r,
                                              const double *__restrict__ winv_r, LaneState &st,
-                                             double *__restrict__ scores)
+                                             double *__restrict__ scores, const LaneCentre<FLT> &lc,
+                                             double (&margin)[BAND_X])
 {
     const double n = (double)(g.win_w * g.win_h);
     const int64_t srow = (int64_t)wy * g.stride_y * g.nsx;
     // window x at offset d looks at the right-image box xbase + x + d + k0 - max_disp:
     // BAND_X + DN - 1 distinct boxes serve the lane's BAND_X * DN evaluations
     constexpr int NJ = BAND_X + DN - 1;
-    int32_t r_sum[NJ];
+    TSum r_sum[NJ];
     double r_inv[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -428,13 +492,39 @@ __device__ __forceinline__ void finish_range(const BandGeom &g, const float2v (&
             double s = NAN;
             if (wvalid && kvalid) {
                 const float cross = (x & 1) ? acc[x / 2][d].y : acc[x / 2][d].x;
-                const double num = fma(n, (double)cross, -(s1l * (double)r_sum[x + dd]));
+                double cross64 = (double)cross;
+                if constexpr (FLT) {
+                    // the lane's constants back in: sum (l - a)(r - b) = sum l r - b sum l - a sum r + n a b
+                    const double a = (double)lc.a.x, b = (double)lc.b.x;
+                    cross64 += a * (double)r_sum[x + dd] + b * s1l - n * a * b;
+                }
+                const double num = fma(n, cross64, -(s1l * (double)r_sum[x + dd]));
                 s = num * invl * r_inv[x + dd];
             }
             if (scores && wvalid && kvalid)
                 scores[((int64_t)wy * g.nwx + xw) * g.nd + k] = s;
             if (!kvalid)
                 continue;
+            if constexpr (FLT) {
+                // how far this decision is from going the other way
+                if (s == s) {
+                    // Pixels are staged as float32 of (pixel - image mean): a window whose mean
+                    // lies many of its own deviations away from the image mean has lost its
+                    // texture to that rounding (relative error about 2^-23 mean / deviation per
+                    // pixel).  Such an evaluation sends its window to the float64 second look.
+                    const double lost = 1.2e-7 * (fabs(s1l) * invl + fabs((double)r_sum[x + dd]) * r_inv[x + dd]);
+                    if (lost > 4e-6)
+                        margin[x] = 0.0;
+                    double m = INFINITY;
+                    if (g.mode == SVAMD_BAND_ARGMAX)
+                        m = fabs(s - st.best[x]);
+                    else if (centre_pass)
+                        m = fmin(fabs(s - g.thr), fabs(s - st.best[x]));
+                    else if (k != g.max_disp)
+                        m = fmin(fabs(s - g.thr), fabs(s - (st.best[x] + g.tol)));
+                    margin[x] = fmin(margin[x], m);
+                }
+            }
             if (g.mode == SVAMD_BAND_ARGMAX) {
                 if (s > st.best[x]) {
                     st.best[x] = s;
@@ -460,21 +550,25 @@ __device__ __forceinline__ void finish_range(const BandGeom &g, const float2v (&
 // accumulators are dead before the second half's statistics arrive, which keeps
 // the epilogue inside the register budget the accumulation loop leaves (every
 // window still sees its offsets in ascending order).
-template <int D>
+template <int D, bool FLT, typename TSum>
 __device__ __forceinline__ void finish_pass(const BandGeom &g, const float2v (&acc)[BAND_X / 2][D], int k0,
                                             int kend, bool centre_pass, int wy, int xbase,
-                                            const int32_t *__restrict__ wsum_l,
+                                            const TSum *__restrict__ wsum_l,
                                             const double *__restrict__ winv_l,
-                                            const int32_t *__restrict__ wsum_r,
+                                            const TSum *__restrict__ wsum_r,
                                             const double *__restrict__ winv_r, LaneState &st,
-                                            double *__restrict__ scores)
+                                            double *__restrict__ scores, const LaneCentre<FLT> &lc,
+                                            double (&margin)[BAND_X])
 {
     if constexpr (D == 8) {
-        finish_range<D, 0, 4>(g, acc, k0, kend, centre_pass, wy, xbase, wsum_l, winv_l, wsum_r, winv_r, st, scores);
+        finish_range<D, 0, 4, FLT>(g, acc, k0, kend, centre_pass, wy, xbase, wsum_l, winv_l, wsum_r, winv_r, st,
+                                   scores, lc, margin);
         __builtin_amdgcn_sched_barrier(0);
-        finish_range<D, 4, 4>(g, acc, k0, kend, centre_pass, wy, xbase, wsum_l, winv_l, wsum_r, winv_r, st, scores);
+        finish_range<D, 4, 4, FLT>(g, acc, k0, kend, centre_pass, wy, xbase, wsum_l, winv_l, wsum_r, winv_r, st,
+                                   scores, lc, margin);
     } else {
-        finish_range<D, 0, D>(g, acc, k0, kend, centre_pass, wy, xbase, wsum_l, winv_l, wsum_r, winv_r, st, scores);
+        finish_range<D, 0, D, FLT>(g, acc, k0, kend, centre_pass, wy, xbase, wsum_l, winv_l, wsum_r, winv_r, st,
+                                   scores, lc, margin);
     }
 }
 
@@ -521,13 +615,17 @@ __device__ __forceinline__ void keep_pace(volatile int *progress, int wave, int 
 #define SV_SCORES_OUT scores
 #endif
 
-template <int WIN_W>
+template <int WIN_W, typename PIX>
 __global__ void __launch_bounds__(BAND_THREADS)
-band_scan_kernel(BandGeom g, const uint8_t *__restrict__ left, const uint8_t *__restrict__ right,
-                 const int32_t *__restrict__ wsum_l, const double *__restrict__ winv_l,
-                 const int32_t *__restrict__ wsum_r, const double *__restrict__ winv_r,
-                 int32_t *__restrict__ out_disp, double *__restrict__ out_val, double *__restrict__ scores)
+band_scan_kernel(BandGeom g, const PIX *__restrict__ left, const PIX *__restrict__ right,
+                 const typename std::conditional<std::is_same<PIX, uint8_t>::value, int32_t, double>::type *__restrict__ wsum_l,
+                 const double *__restrict__ winv_l,
+                 const typename std::conditional<std::is_same<PIX, uint8_t>::value, int32_t, double>::type *__restrict__ wsum_r,
+                 const double *__restrict__ winv_r,
+                 int32_t *__restrict__ out_disp, double *__restrict__ out_val, double *__restrict__ scores,
+                 const Stats *__restrict__ image_stats, double *__restrict__ out_margin)
 {
+    constexpr bool FLT = !std::is_same<PIX, uint8_t>::value;
     extern __shared__ __align__(16) float tile[];
     __shared__ int progress[BAND_WAVES];
     float *Lt = tile;
@@ -548,14 +646,41 @@ band_scan_kernel(BandGeom g, const uint8_t *__restrict__ left, const uint8_t *__
     __builtin_amdgcn_s_setprio(3);                  // everyone starts level; leaders step down
 
     LaneState st;
+    double margin[BAND_X];
 #pragma unroll
     for (int x = 0; x < BAND_X; ++x) {
         st.best[x] = g.mode == SVAMD_BAND_ARGMAX ? -INFINITY : 0.0;
         st.arg[x] = g.mode == SVAMD_BAND_ARGMAX ? SVAMD_BAND_NO_MATCH : 0;
+        margin[x] = INFINITY;
+    }
+
+    // floating-point images: the image means the staged pixels are centred by, and the
+    // constants this lane takes off what it reads (see the head of the file)
+    double centre_l = 128.0, centre_r = 128.0;
+    LaneCentre<FLT> lc;
+    const double inv_n = 1.0 / (double)(g.win_w * g.win_h);
+    const int64_t srow = active ? (int64_t)wy * g.stride_y * g.nsx : 0;
+    auto right_constant = [&](int k) {           // about the mean of the boxes around offset index k
+        if constexpr (FLT) {
+            const int xr = min(max(xbase + BAND_X / 2 + k - g.max_disp, 0), g.nsx - 1);
+            float b = active ? (float)((double)wsum_r[srow + xr] * inv_n) : 0.f;
+            if (!(fabsf(b) < 3.0e38f))
+                b = 0.f;
+            lc.b = float2v{b, b};
+        }
+    };
+    if constexpr (FLT) {
+        centre_l = image_stats[0].mean;
+        centre_r = image_stats[1].mean;
+        float a = active ? (float)((double)wsum_l[srow + min(xbase + BAND_X / 2, g.nwx - 1)] * inv_n) : 0.f;
+        if (!(fabsf(a) < 3.0e38f))
+            a = 0.f;
+        lc.a = float2v{a, a};
+        lc.b = float2v{0.f, 0.f};
     }
 
     SV_STAMP(0);
-    stage_tile(left, g.H, g.W, y0, g.tile_rows, x0, g.lpitch, Lt);
+    stage_tile(left, g.H, g.W, y0, g.tile_rows, x0, g.lpitch, Lt, centre_l);
     const float *lp = Lt + lrow * g.lpitch + BAND_X * lane;
 
     // The centre offset is judged first (selection-rule mode).  When the whole offset
@@ -563,44 +688,55 @@ band_scan_kernel(BandGeom g, const uint8_t *__restrict__ left, const uint8_t *__
     // staged at d = 0 for it.
     const bool whole_band = g.dchunk >= g.nd;
     if (g.mode == SVAMD_BAND_FOLD && !whole_band) {
-        stage_tile(right, g.H, g.W, y0, g.tile_rows, x0, g.lpitch, Rt);
+        stage_tile(right, g.H, g.W, y0, g.tile_rows, x0, g.lpitch, Rt, centre_r);
         __syncthreads();
         if (active) {
             float2v acc[BAND_X / 2][1] = {};
-            accumulate_rows<WIN_W, 1, true>(lp, Rt + lrow * g.lpitch + BAND_X * lane, g.lpitch, g.lpitch,
-                                            g.win_h, g.win_w, acc);
-            finish_pass<1>(g, acc, g.max_disp, g.nd, true, wy, xbase, wsum_l, winv_l, wsum_r, winv_r, st, nullptr);
+            right_constant(g.max_disp);
+            accumulate_rows<WIN_W, 1, true, FLT>(lp, Rt + lrow * g.lpitch + BAND_X * lane, g.lpitch, g.lpitch,
+                                                 g.win_h, g.win_w, acc, lc);
+            finish_pass<1, FLT>(g, acc, g.max_disp, g.nd, true, wy, xbase, wsum_l, winv_l, wsum_r, winv_r, st,
+                                nullptr, lc, margin);
         }
     }
 
     for (int k0 = 0; k0 < g.nd; k0 += g.dchunk) {
         const int kend = min(k0 + g.dchunk, g.nd);
         __syncthreads();  // previous contents of Rt are no longer read
-        stage_tile(right, g.H, g.W, y0, g.tile_rows, x0 - g.max_disp + k0, g.rpitch, Rt);
+        stage_tile(right, g.H, g.W, y0, g.tile_rows, x0 - g.max_disp + k0, g.rpitch, Rt, centre_r);
         __syncthreads();
         if (!active)
             continue;
         const float *rp = Rt + lrow * g.rpitch + BAND_X * lane;
         if (g.mode == SVAMD_BAND_FOLD && whole_band) {
             float2v acc[BAND_X / 2][1] = {};
+            right_constant(g.max_disp);
             if (g.max_disp & 3)
-                accumulate_rows<WIN_W, 1, false>(lp, rp + g.max_disp, g.lpitch, g.rpitch, g.win_h, g.win_w, acc);
+                accumulate_rows<WIN_W, 1, false, FLT>(lp, rp + g.max_disp, g.lpitch, g.rpitch, g.win_h, g.win_w,
+                                                      acc, lc);
             else
-                accumulate_rows<WIN_W, 1, true>(lp, rp + g.max_disp, g.lpitch, g.rpitch, g.win_h, g.win_w, acc);
-            finish_pass<1>(g, acc, g.max_disp, g.nd, true, wy, xbase, wsum_l, winv_l, wsum_r, winv_r, st, nullptr);
+                accumulate_rows<WIN_W, 1, true, FLT>(lp, rp + g.max_disp, g.lpitch, g.rpitch, g.win_h, g.win_w,
+                                                     acc, lc);
+            finish_pass<1, FLT>(g, acc, g.max_disp, g.nd, true, wy, xbase, wsum_l, winv_l, wsum_r, winv_r, st,
+                                nullptr, lc, margin);
         }
         int k = k0;
         for (; k + BAND_D <= kend; k += BAND_D) {
             float2v acc[BAND_X / 2][BAND_D] = {};
-            accumulate_rows<WIN_W, BAND_D, true>(lp, rp + (k - k0), g.lpitch, g.rpitch, g.win_h, g.win_w, acc);
-            finish_pass<BAND_D>(g, acc, k, kend, false, wy, xbase, wsum_l, winv_l, wsum_r, winv_r, st, SV_SCORES_OUT);
+            right_constant(k + BAND_D / 2);
+            accumulate_rows<WIN_W, BAND_D, true, FLT>(lp, rp + (k - k0), g.lpitch, g.rpitch, g.win_h, g.win_w, acc,
+                                                      lc);
+            finish_pass<BAND_D, FLT>(g, acc, k, kend, false, wy, xbase, wsum_l, winv_l, wsum_r, winv_r, st,
+                                     SV_SCORES_OUT, lc, margin);
             keep_pace(progress, wave, ++passes);
             SV_STAMP(1 + k / BAND_D);
         }
         for (; k < kend; ++k) {  // fewer than 8 offsets left in this chunk
             float2v acc[BAND_X / 2][1] = {};
-            accumulate_rows<WIN_W, 1, false>(lp, rp + (k - k0), g.lpitch, g.rpitch, g.win_h, g.win_w, acc);
-            finish_pass<1>(g, acc, k, kend, false, wy, xbase, wsum_l, winv_l, wsum_r, winv_r, st, SV_SCORES_OUT);
+            right_constant(k);
+            accumulate_rows<WIN_W, 1, false, FLT>(lp, rp + (k - k0), g.lpitch, g.rpitch, g.win_h, g.win_w, acc, lc);
+            finish_pass<1, FLT>(g, acc, k, kend, false, wy, xbase, wsum_l, winv_l, wsum_r, winv_r, st,
+                                SV_SCORES_OUT, lc, margin);
         }
     }
 
@@ -615,7 +751,146 @@ band_scan_kernel(BandGeom g, const uint8_t *__restrict__ left, const uint8_t *__
                 out_disp[o] = st.arg[x];
                 out_val[o] = (g.mode == SVAMD_BAND_ARGMAX && st.arg[x] == SVAMD_BAND_NO_MATCH) ? NAN
                                                                                                : st.best[x];
+                if constexpr (FLT)
+                    out_margin[o] = margin[x];
             }
+        }
+    }
+}
+
+// ---- floating-point images: statistics, and the float64 second look -------------------
+// Window sums and 1 / sqrt(A) from float64 tables of the centred pixels.  A is a
+// difference of table entries whose rounding follows the image's size, not the window's:
+// a window whose A is not far above that rounding (a flat patch of a large image) takes
+// its sums from its own pixels, and counts as constant (NaN scores) only when all of them
+// are equal.
+__global__ void __launch_bounds__(256)
+window_stats_f64_kernel(const double *__restrict__ img, const Stats *__restrict__ image_stats,
+                        const double *__restrict__ s1, const double *__restrict__ s2, int H, int W, int win_w,
+                        int win_h, double *__restrict__ wsum, double *__restrict__ winv)
+{
+    const int nsx = W - win_w + 1, nsy = H - win_h + 1;
+    const int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)nsx * nsy)
+        return;
+    const int y = (int)(idx / nsx), x = (int)(idx - (int64_t)y * nsx);
+    const int64_t tp = (int64_t)W + 1;
+    const int64_t a = (int64_t)y * tp + x, b = (int64_t)(y + win_h) * tp + x;
+    double sum = s1[b + win_w] - s1[a + win_w] - s1[b] + s1[a];
+    const double sq = s2[b + win_w] - s2[a + win_w] - s2[b] + s2[a];
+    const double n = (double)win_w * (double)win_h;
+    double A = n * sq - sum * sum;
+    const double c1 = fmax(fmax(fabs(s1[a]), fabs(s1[a + win_w])), fmax(fabs(s1[b]), fabs(s1[b + win_w])));
+    const double c2 = fmax(fmax(fabs(s2[a]), fabs(s2[a + win_w])), fmax(fabs(s2[b]), fabs(s2[b + win_w])));
+    const double ulp = 2.220446049250313e-16 * (n * c2 + 2.0 * fabs(sum) * c1);
+    bool flat = false;
+    if (!(A > 1e7 * ulp)) {
+        const double centre = image_stats->mean;
+        double lo = INFINITY, hi = -INFINITY;
+        sum = 0.0;
+        for (int r = 0; r < win_h; ++r)
+            for (int c = 0; c < win_w; ++c) {
+                const double p = img[(int64_t)(y + r) * W + x + c];
+                sum += p - centre;
+                lo = fmin(lo, p);
+                hi = fmax(hi, p);
+            }
+        const double mean = sum / n;
+        double dev = 0.0;
+        for (int r = 0; r < win_h; ++r)
+            for (int c = 0; c < win_w; ++c) {
+                const double d = img[(int64_t)(y + r) * W + x + c] - centre - mean;
+                dev += d * d;
+            }
+        A = n * dev;                      // n * sum (p - mean)^2 = n * sq - sum^2
+        flat = lo == hi;
+    }
+    wsum[idx] = sum;
+    winv[idx] = (A > 0.0 && !flat) ? 1.0 / sqrt(A) : NAN;
+}
+
+__global__ void __launch_bounds__(256)
+band_collect_close_kernel(const double *__restrict__ margin, int nwx, int row_begin, int row_end, double guard,
+                          int32_t *__restrict__ list, int32_t *__restrict__ count)
+{
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t first = (int64_t)row_begin * nwx, total = (int64_t)(row_end - row_begin) * nwx;
+    if (i >= total || !(margin[first + i] < guard))
+        return;
+    list[atomicAdd(count, 1)] = (int32_t)(first + i);
+}
+
+// The windows on the list once more, every offset in float64 straight from the images
+// (one wavefront per window, a lane per offset), then the same selection.  The window
+// statistics are the tables' (they are float64 already); only the cross term differs.
+__global__ void __launch_bounds__(WAVE)
+band_recheck_kernel(BandGeom g, const double *__restrict__ left, const double *__restrict__ right,
+                    const Stats *__restrict__ image_stats, const double *__restrict__ wsum_l,
+                    const double *__restrict__ winv_l, const double *__restrict__ wsum_r,
+                    const double *__restrict__ winv_r, const int32_t *__restrict__ list,
+                    const int32_t *__restrict__ count, int32_t *__restrict__ out_disp,
+                    double *__restrict__ out_val, double *__restrict__ scores)
+{
+    extern __shared__ __align__(16) double sc[];
+    const int lane = threadIdx.x;
+    const double centre_l = image_stats[0].mean, centre_r = image_stats[1].mean;
+    const double n = (double)(g.win_w * g.win_h);
+    const int todo = *count;
+    for (int item = blockIdx.x; item < todo; item += gridDim.x) {
+        const int64_t o = list[item];
+        const int wy = (int)(o / g.nwx), wx = (int)(o - (int64_t)wy * g.nwx);
+        const int y = wy * g.stride_y;
+        const int64_t srow = (int64_t)y * g.nsx;
+        const double s1l = wsum_l[srow + wx], invl = winv_l[srow + wx];
+        __syncthreads();                       // the previous window's scores have been read
+        for (int k = lane; k < g.nd; k += WAVE) {
+            const int xr = wx + k - g.max_disp;
+            double s = NAN;
+            if (xr >= 0 && xr < g.nsx) {
+                double cross = 0.0;
+                for (int r = 0; r < g.win_h; ++r) {
+                    const double *lrow = left + (int64_t)(y + r) * g.W + wx;
+                    const double *rrow = right + (int64_t)(y + r) * g.W + xr;
+                    for (int c = 0; c < g.win_w; ++c)
+                        cross = fma(lrow[c] - centre_l, rrow[c] - centre_r, cross);
+                }
+                s = fma(n, cross, -(s1l * wsum_r[srow + xr])) * invl * winv_r[srow + xr];
+            }
+            sc[k] = s;
+            if (scores)
+                scores[o * g.nd + k] = s;
+        }
+        __syncthreads();
+        if (lane == 0) {
+            double best;
+            int arg;
+            if (g.mode == SVAMD_BAND_ARGMAX) {
+                best = -INFINITY;
+                arg = SVAMD_BAND_NO_MATCH;
+                for (int k = 0; k < g.nd; ++k)
+                    if (sc[k] > best) {
+                        best = sc[k];
+                        arg = k - g.max_disp;
+                    }
+                if (arg == SVAMD_BAND_NO_MATCH)
+                    best = NAN;
+            } else {
+                best = 0.0;
+                arg = 0;
+                const double c = sc[g.max_disp];
+                if (c > g.thr && c >= best)
+                    best = c;
+                for (int k = 0; k < g.nd; ++k) {
+                    if (k == g.max_disp)
+                        continue;
+                    if (sc[k] > g.thr && sc[k] > best + g.tol) {
+                        best = sc[k];
+                        arg = k - g.max_disp;
+                    }
+                }
+            }
+            out_disp[o] = arg;
+            out_val[o] = best;
         }
     }
 }
@@ -631,18 +906,47 @@ static BandWs band_ws(int H, int W, int win_w, int win_h)
     return b;
 }
 
-template <int WIN_W>
-static int band_launch(const BandGeom &g, size_t lds, dim3 grid, hipStream_t st, const uint8_t *left,
-                       const uint8_t *right, const int32_t *wl, const double *il, const int32_t *wr,
-                       const double *ir, int32_t *out_disp, double *out_val, double *scores)
+template <int WIN_W, typename PIX, typename TSum>
+static int band_launch(const BandGeom &g, size_t lds, dim3 grid, hipStream_t st, const PIX *left,
+                       const PIX *right, const TSum *wl, const double *il, const TSum *wr,
+                       const double *ir, int32_t *out_disp, double *out_val, double *scores,
+                       const Stats *image_stats = nullptr, double *out_margin = nullptr)
 {
     // per function and per device: set before every launch (a process may drive several devices)
-    SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&band_scan_kernel<WIN_W>),
+    SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&band_scan_kernel<WIN_W, PIX>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, BAND_LDS_LIMIT));
-    hipLaunchKernelGGL((band_scan_kernel<WIN_W>), grid, dim3(BAND_THREADS), lds, st, g, left, right, wl, il,
-                       wr, ir, out_disp, out_val, scores);
+    hipLaunchKernelGGL((band_scan_kernel<WIN_W, PIX>), grid, dim3(BAND_THREADS), lds, st, g, left, right, wl, il,
+                       wr, ir, out_disp, out_val, scores, image_stats, out_margin);
     SV_LAUNCH_CHECK();
     return SVAMD_OK;
+}
+
+// Tile geometry.  Row pitches carry 4 floats of slack because the last 4-wide LDS
+// read of a lane may extend past the columns it uses.  As many offsets as fit in LDS
+// are staged per pass over the right image.  Returns the dynamic LDS size, 0 when
+// the window does not fit.
+static size_t band_tile_geometry(BandGeom &g, bool tuned)
+{
+    const int slack = tuned ? 4 : 12;   // the run-time-width row walk reads up to three quads ahead
+    g.lpitch = (int)align_up((size_t)(BAND_TX + g.win_w - 1), 4) + slack;
+    size_t lds = 0;
+    for (g.tile_wrows = BAND_WAVES; g.tile_wrows >= 1; --g.tile_wrows) {
+        g.tile_rows = (g.tile_wrows - 1) * g.stride_y + g.win_h;
+        g.dchunk = (int)align_up((size_t)g.nd, BAND_D);
+        for (;;) {
+            const int dcur = g.dchunk < g.nd ? g.dchunk : g.nd;
+            g.rpitch = (int)align_up((size_t)(BAND_TX + g.win_w - 1 + dcur - 1), 4) + slack;
+            if (g.rpitch < g.lpitch)
+                g.rpitch = g.lpitch;  // the centre pass stages a left-shaped tile into Rt
+            lds = (size_t)g.tile_rows * (g.lpitch + g.rpitch) * sizeof(float);
+            if (lds <= (size_t)BAND_LDS_LIMIT || g.dchunk <= BAND_D)
+                break;
+            g.dchunk -= BAND_D;
+        }
+        if (lds <= (size_t)BAND_LDS_LIMIT)
+            break;
+    }
+    return lds <= (size_t)BAND_LDS_LIMIT ? lds : 0;
 }
 
 }  // namespace svamd
@@ -747,30 +1051,9 @@ extern "C" int svamd_band_scan_u8(const uint8_t *left, const uint8_t *right, int
     if (row_begin == row_end)
         return SVAMD_OK;
 
-    // Tile geometry.  Row pitches carry 4 floats of slack because the last
-    // 4-wide LDS read of a lane may extend past the columns it uses.  As many
-    // offsets as fit in LDS are staged per pass over the right image.
     const bool tuned = win_w == 7 || win_w == 11 || win_w == 15 || win_w == 21 || win_w == 25 || win_w == 31;
-    const int slack = tuned ? 4 : 12;   // the run-time-width row walk reads up to three quads ahead
-    g.lpitch = (int)align_up((size_t)(BAND_TX + win_w - 1), 4) + slack;
-    size_t lds = 0;
-    for (g.tile_wrows = BAND_WAVES; g.tile_wrows >= 1; --g.tile_wrows) {
-        g.tile_rows = (g.tile_wrows - 1) * stride_y + win_h;
-        g.dchunk = (int)align_up((size_t)g.nd, BAND_D);
-        for (;;) {
-            const int dcur = g.dchunk < g.nd ? g.dchunk : g.nd;
-            g.rpitch = (int)align_up((size_t)(BAND_TX + win_w - 1 + dcur - 1), 4) + slack;
-            if (g.rpitch < g.lpitch)
-                g.rpitch = g.lpitch;  // the centre pass stages a left-shaped tile into Rt
-            lds = (size_t)g.tile_rows * (g.lpitch + g.rpitch) * sizeof(float);
-            if (lds <= (size_t)BAND_LDS_LIMIT || g.dchunk <= BAND_D)
-                break;
-            g.dchunk -= BAND_D;
-        }
-        if (lds <= (size_t)BAND_LDS_LIMIT)
-            break;
-    }
-    SV_REQUIRE(lds <= (size_t)BAND_LDS_LIMIT, SVAMD_ERR_LIMIT,
+    const size_t lds = band_tile_geometry(g, tuned);
+    SV_REQUIRE(lds > 0, SVAMD_ERR_LIMIT,
                "band_scan_u8: window %dx%d with row stride %d does not fit the LDS tile", win_w, win_h,
                stride_y);
 
@@ -799,4 +1082,151 @@ extern "C" int svamd_band_scan_u8(const uint8_t *left, const uint8_t *right, int
         return band_launch<0>(g, lds, grid, st, left, right, wl, il, wr, ir, out_disp, out_val, scores);
     }
 #undef SV_BAND_CASE
+}
+
+// ---- the same scan for float64 images ------------------------------------------------
+namespace {
+struct BandTablesF {
+    Stats *stats;          // [0] left image, [1] right image
+    double *sscr;
+    double *s1l, *s2l, *s1r, *s2r, *wl, *wr, *il, *ir, *margin;
+    int32_t *list, *count;
+    size_t bytes;
+};
+BandTablesF band_tables_f(void *workspace, int H, int W, int win_w, int win_h)
+{
+    BandWs b = band_ws(H, W, win_w, win_h);
+    Carver ws(workspace);
+    BandTablesF t;
+    t.stats = ws.take<Stats>(2);
+    t.sscr = ws.take<double>(stats_scratch_doubles());
+    t.s1l = ws.take<double>(b.n_sat);
+    t.s2l = ws.take<double>(b.n_sat);
+    t.s1r = ws.take<double>(b.n_sat);
+    t.s2r = ws.take<double>(b.n_sat);
+    t.wl = ws.take<double>(b.n_stat);
+    t.wr = ws.take<double>(b.n_stat);
+    t.il = ws.take<double>(b.n_stat);
+    t.ir = ws.take<double>(b.n_stat);
+    t.margin = ws.take<double>(b.n_stat);
+    t.list = ws.take<int32_t>(b.n_stat);
+    t.count = ws.take<int32_t>(64);
+    t.bytes = ws.used;
+    return t;
+}
+}  // namespace
+
+extern "C" size_t svamd_band_scan_f64_workspace_bytes(int H, int W, int win_w, int win_h)
+{
+    if (H <= 0 || W <= 0 || win_w <= 0 || win_h <= 0 || win_w > W || win_h > H)
+        return 0;
+    return band_tables_f(nullptr, H, W, win_w, win_h).bytes;
+}
+
+extern "C" int svamd_band_prepare_f64(const double *left, const double *right, int H, int W, int win_w,
+                                      int win_h, void *workspace, size_t workspace_bytes, void *stream)
+{
+    SV_REQUIRE(left && right, SVAMD_ERR_INVALID, "band_prepare_f64: NULL pointer");
+    SV_REQUIRE(H > 0 && W > 0 && win_w > 0 && win_h > 0, SVAMD_ERR_INVALID, "band_prepare_f64: non-positive size");
+    SV_REQUIRE(win_w <= W && win_h <= H, SVAMD_ERR_SHAPE,
+               "Dimensions of template must not exceed those of region.");
+    SV_REQUIRE((int64_t)(H + 1) * (W + 1) < (1LL << 31), SVAMD_ERR_LIMIT, "band_prepare_f64: image too large");
+    SV_REQUIRE(workspace && (reinterpret_cast<uintptr_t>(workspace) & 255) == 0 &&
+                   workspace_bytes >= svamd_band_scan_f64_workspace_bytes(H, W, win_w, win_h),
+               SVAMD_ERR_WORKSPACE, "band_prepare_f64: workspace missing, misaligned or too small");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    BandWs b = band_ws(H, W, win_w, win_h);
+    BandTablesF t = band_tables_f(workspace, H, W, win_w, win_h);
+    int rc;
+    if ((rc = stats_launch(left, SVAMD_F64, H, W, W, false, t.stats, t.sscr, st)) != SVAMD_OK) return rc;
+    if ((rc = stats_launch(right, SVAMD_F64, H, W, W, false, t.stats + 1, t.sscr, st)) != SVAMD_OK) return rc;
+    // (the window statistics are written after the tables: until then their buffer is the tables' scratch)
+    const size_t spare = b.n_stat * sizeof(double);
+    if ((rc = sat2d_launch<double, double>(left, H, W, W, 0.0, t.s1l, t.s2l, st, t.il, spare, &t.stats[0].mean)) !=
+        SVAMD_OK)
+        return rc;
+    if ((rc = sat2d_launch<double, double>(right, H, W, W, 0.0, t.s1r, t.s2r, st, t.ir, spare, &t.stats[1].mean)) !=
+        SVAMD_OK)
+        return rc;
+    const unsigned sg = (unsigned)((b.n_stat + 255) / 256);
+    hipLaunchKernelGGL(window_stats_f64_kernel, dim3(sg), dim3(256), 0, st, left, t.stats, t.s1l, t.s2l, H, W, win_w,
+                       win_h, t.wl, t.il);
+    SV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(window_stats_f64_kernel, dim3(sg), dim3(256), 0, st, right, t.stats + 1, t.s1r, t.s2r, H, W,
+                       win_w, win_h, t.wr, t.ir);
+    SV_LAUNCH_CHECK();
+    return SVAMD_OK;
+}
+
+extern "C" int svamd_band_scan_f64(const double *left, const double *right, int H, int W, int win_w, int win_h,
+                                   int stride_x, int stride_y, int max_disp, int mode, double threshold,
+                                   double centre_tol, double guard_band, int row_begin, int row_end, int flags,
+                                   int32_t *out_disp, double *out_val, double *scores, void *workspace,
+                                   size_t workspace_bytes, void *stream)
+{
+    SV_REQUIRE(left && right && out_disp && out_val, SVAMD_ERR_INVALID, "band_scan_f64: NULL pointer");
+    SV_REQUIRE(H > 0 && W > 0 && win_w > 0 && win_h > 0 && max_disp >= 0 && stride_y > 0, SVAMD_ERR_INVALID,
+               "band_scan_f64: non-positive size");
+    SV_REQUIRE(win_w <= W && win_h <= H, SVAMD_ERR_SHAPE,
+               "Dimensions of template must not exceed those of region.");
+    SV_REQUIRE(mode == SVAMD_BAND_ARGMAX || mode == SVAMD_BAND_FOLD, SVAMD_ERR_INVALID,
+               "band_scan_f64: unknown mode %d", mode);
+    SV_REQUIRE(stride_x == 1, SVAMD_ERR_LIMIT, "band_scan_f64: only stride_x == 1 is supported (got %d)",
+               stride_x);
+    SV_REQUIRE((int64_t)win_w * win_h <= 4096, SVAMD_ERR_LIMIT, "band_scan_f64: window area %d exceeds 4096",
+               win_w * win_h);
+    SV_REQUIRE((int64_t)(H + 1) * (W + 1) < (1LL << 31), SVAMD_ERR_LIMIT, "band_scan_f64: image too large");
+    SV_REQUIRE(guard_band >= 0.0, SVAMD_ERR_INVALID, "band_scan_f64: negative guard band");
+    SV_REQUIRE(workspace && (reinterpret_cast<uintptr_t>(workspace) & 255) == 0 &&
+                   workspace_bytes >= svamd_band_scan_f64_workspace_bytes(H, W, win_w, win_h),
+               SVAMD_ERR_WORKSPACE, "band_scan_f64: workspace missing, misaligned or too small");
+    BandGeom g;
+    g.H = H; g.W = W; g.win_w = win_w; g.win_h = win_h; g.stride_y = stride_y; g.max_disp = max_disp;
+    g.nd = 2 * max_disp + 1;
+    g.nwx = W - win_w + 1;
+    g.nwy = (H - win_h) / stride_y + 1;
+    g.nsx = W - win_w + 1;
+    g.mode = mode; g.thr = threshold; g.tol = centre_tol;
+    SV_REQUIRE(row_begin >= 0 && row_begin <= row_end && row_end <= g.nwy, SVAMD_ERR_INVALID,
+               "band_scan_f64: row range [%d, %d) outside 0..%d", row_begin, row_end, g.nwy);
+    g.row_begin = row_begin; g.row_end = row_end;
+    if (row_begin == row_end)
+        return SVAMD_OK;
+    const bool tuned = win_w == 25 || win_w == 31;
+    const size_t lds = band_tile_geometry(g, tuned);
+    SV_REQUIRE(lds > 0, SVAMD_ERR_LIMIT, "band_scan_f64: window %dx%d with row stride %d does not fit the LDS tile",
+               win_w, win_h, stride_y);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int rc;
+    if (!(flags & SVAMD_BAND_PREPARED) &&
+        (rc = svamd_band_prepare_f64(left, right, H, W, win_w, win_h, workspace, workspace_bytes, stream)) != SVAMD_OK)
+        return rc;
+    BandTablesF t = band_tables_f(workspace, H, W, win_w, win_h);
+    // the margins are indexed by window (row of the window grid), the statistics by image position
+    dim3 grid((g.nwx + BAND_TX - 1) / BAND_TX, (row_end - row_begin + g.tile_wrows - 1) / g.tile_wrows);
+    switch (win_w) {
+    case 25:
+        rc = band_launch<25>(g, lds, grid, st, left, right, t.wl, t.il, t.wr, t.ir, out_disp, out_val, scores, t.stats,
+                             t.margin);
+        break;
+    case 31:
+        rc = band_launch<31>(g, lds, grid, st, left, right, t.wl, t.il, t.wr, t.ir, out_disp, out_val, scores, t.stats,
+                             t.margin);
+        break;
+    default:
+        rc = band_launch<0>(g, lds, grid, st, left, right, t.wl, t.il, t.wr, t.ir, out_disp, out_val, scores, t.stats,
+                            t.margin);
+    }
+    if (rc != SVAMD_OK || guard_band == 0.0)
+        return rc;
+    SV_HIP(hipMemsetAsync(t.count, 0, 64 * sizeof(int32_t), st));
+    const int64_t total = (int64_t)(row_end - row_begin) * g.nwx;
+    hipLaunchKernelGGL(band_collect_close_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, t.margin,
+                       g.nwx, row_begin, row_end, guard_band, t.list, t.count);
+    SV_LAUNCH_CHECK();
+    const unsigned rgrid = (unsigned)(total < 32768 ? total : 32768);
+    hipLaunchKernelGGL(band_recheck_kernel, dim3(rgrid), dim3(WAVE), (size_t)g.nd * sizeof(double), st, g, left, right,
+                       t.stats, t.wl, t.il, t.wr, t.ir, t.list, t.count, out_disp, out_val, scores);
+    SV_LAUNCH_CHECK();
+    return SVAMD_OK;
 }

@@ -266,3 +266,33 @@ def test_dense_scan_through_sequence_scan(oracle):
         assert (info['row'], info['column'], info['centre']) == (row, column, centre)
         assert len(info['target_regions']) == len(regions)
         assert (info['dp_x'], info['dp_y']) == (pos[0] - centre[0], pos[1] - centre[1]), window_id
+
+
+def test_dense_float_scan_after_downsample_matches_the_oracle(oracle):
+    '''The dense scan after the reference's own preprocessing: the 4096 x 4096 pair
+    through utils.downsample(image, 2) (float64 pixels that are no 8-bit levels any
+    more), then the band scan of the 2048 x 2048 results - bands of window rows at the
+    top, in the middle and at the bottom against the oracle's float64 scan: disparities
+    exactly, correlations to the float32 bar.'''
+    import contextlib
+    import io
+    import band_scan as bs
+    import bench
+    import utils
+    left, right = bench.synthetic_pair(4096, 4096, seed=1000)
+    with contextlib.redirect_stdout(io.StringIO()):
+        left, right = np.asarray(utils.downsample(left, 2)), np.asarray(utils.downsample(right, 2))
+    with pytest.raises(TypeError):
+        bs.as_uint8_image(left)
+    scanner = bs.BandScanner(2048, 2048, WIN, WIN, 64)
+    scanner.upload(left, right)
+    assert scanner.kind == 'f64'
+    scanner.run(THRESHOLD)
+    disp, val = scanner.disp.cpu().numpy(), scanner.val.cpu().numpy()
+    rows = 4
+    for row0 in (0, 1009, 2018 - rows):
+        crop = slice(row0, row0 + rows + WIN - 1)
+        odisp, oval = oracle.band_scan(left[crop], right[crop], WIN, WIN, 64, mode='fold', threshold=THRESHOLD)
+        assert np.array_equal(disp[row0:row0 + rows], odisp), row0
+        assert_surface_close(val[row0:row0 + rows], oval, 1e-5, 'float band values')
+    assert (disp != 0).mean() > 0.5

@@ -856,8 +856,11 @@ def test_band_scan_takes_the_loaders_output(mods):
     for scaled in ((u.downsample(left, 1), u.downsample(right, 1)), (left / 255.0, right / 255.0)):
         got = b.band_scan(scaled[0], scaled[1], 15, 15, 8)
         assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1], equal_nan=True)
-    with pytest.raises(TypeError):
-        b.band_scan(left / 254.0, right / 254.0, 15, 15, 8)
+    # anything else is scanned as the floating-point image it is: same disparities here
+    # (a rescaling does not change a normalised correlation), values to float32 accuracy
+    got = b.band_scan(left / 254.0, right / 254.0, 15, 15, 8)
+    assert np.array_equal(got[0], want[0])
+    assert_surface_close(got[1], want[1], SURFACE_TOL, 'rescaled pair')
 
 
 def test_band_scan_row_stride_and_sharding(mods, oracle):
@@ -899,10 +902,74 @@ def test_g14_band_fold_matches_reference_rule(mods):
                                                       correlation_threshold=thr))
 
 
+def smooth_float_pair(h, w, seed, shift, contrast=1.0, offset=0.0):
+    '''A float64 pair in the style of a downsampled photograph: smooth texture on top of
+    large-scale brightness changes (window means far from the image mean), the right
+    image displaced by `shift` plus a little noise.'''
+    rng = np.random.default_rng(seed)
+    base = rng.random((h, w + 2 * abs(shift) + 8))
+    for _ in range(2):
+        base = (np.roll(base, 1, 1) + 2 * base + np.roll(base, -1, 1)) / 4
+        base = (np.roll(base, 1, 0) + 2 * base + np.roll(base, -1, 0)) / 4
+    yy, xx = np.mgrid[0:h, 0:base.shape[1]]
+    base = offset + contrast * (0.35 * base + 0.3 * np.sin(xx / 37.0) * np.cos(yy / 23.0) + 0.3)
+    left = base[:, abs(shift):abs(shift) + w].copy()
+    right = base[:, abs(shift) - shift:abs(shift) - shift + w] + contrast * 0.004 * rng.standard_normal((h, w))
+    return left, right
+
+
+@pytest.mark.parametrize('win,h,w,md,stride', [(31, 80, 420, 24, 1), (25, 70, 300, 40, 2), (12, 40, 280, 9, 1),
+                                               (9, 33, 90, 5, 1)])
+def test_band_scan_float_images_vs_oracle(mods, oracle, win, h, w, md, stride):
+    '''Floating-point images (no 8-bit levels: what downsample() returns for factors above
+    1) through svamd_band_scan_f64: disparities exactly as the float64 oracle in both
+    selection modes, values and the score volume to the float32 bar.'''
+    b = mods['b']
+    left, right = smooth_float_pair(h, w, win * 7 + md, 5)
+    disp, val, scores = b.band_scan(left, right, win, win, md, row_stride=stride, want_scores=True)
+    odisp, oval, oscores = oracle.band_scan(left, right, win, win, md, stride_y=stride, want_scores=True)
+    assert_surface_close(scores, oscores, SURFACE_TOL, 'float band scores')
+    assert np.array_equal(disp, odisp)
+    assert_surface_close(val, oval, SURFACE_TOL, 'float band values')
+    assert (disp == 5).mean() > 0.5
+    for thr in (0.5, 0.97):
+        disp, val = b.band_scan(left, right, win, win, md, correlation_threshold=thr, row_stride=stride)
+        odisp, oval = oracle.band_scan(left, right, win, win, md, stride_y=stride, mode='fold', threshold=thr)
+        assert np.array_equal(disp, odisp), thr
+        assert_surface_close(val, oval, SURFACE_TOL, 'float band fold values')
+
+
+def test_band_scan_float_images_hard_cases(mods, oracle):
+    '''What float32 alone would get wrong: a pair far from zero with little contrast
+    (1000 +- 0.02), near-ties between neighbouring offsets of a very smooth image
+    (decided by the float64 second look), an exactly constant patch (NaN scores, as the
+    reference's 0 / 0) and a nearly constant one (finite).'''
+    b = mods['b']
+    left, right = smooth_float_pair(60, 260, 3, -4, contrast=0.05, offset=1000.0)
+    left[10:50, 100:150] = 1000.5
+    left[12:44, 180:240] = 1000.25 + 1e-7 * np.random.default_rng(0).standard_normal((32, 60))
+    for mode, thr in (('argmax', None), ('fold', 0.9)):
+        disp, val, scores = b.band_scan(left, right, 15, 15, 12, correlation_threshold=thr, want_scores=True)
+        odisp, oval, oscores = oracle.band_scan(left, right, 15, 15, 12, mode=mode, threshold=thr or 0.0,
+                                                want_scores=True)
+        assert np.isnan(oscores[12:30, 102:130]).all() and np.isfinite(oscores[14:28, 182:220]).all()
+        assert_surface_close(scores, oscores, SURFACE_TOL, 'hard float band scores')
+        assert np.array_equal(disp, odisp), mode
+        assert_surface_close(val, oval, SURFACE_TOL, 'hard float band values')
+    # a very smooth image: neighbouring offsets score within the guard band of each other
+    rng = np.random.default_rng(8)
+    yy, xx = np.mgrid[0:50, 0:300]
+    smooth = 0.5 + 0.4 * np.sin(xx / 90.0 + yy / 70.0) + 1e-3 * rng.standard_normal((50, 300))
+    disp, val = b.band_scan(smooth, np.roll(smooth, 1, axis=1), 21, 21, 6)
+    odisp, oval = oracle.band_scan(smooth, np.roll(smooth, 1, axis=1), 21, 21, 6)
+    assert np.array_equal(disp, odisp)
+    assert_surface_close(val, oval, SURFACE_TOL, 'smooth float band values')
+
+
 def test_band_scan_rejects_unsupported(mods):
     b = mods['b']
     with pytest.raises(TypeError):
-        b.band_scan(np.random.default_rng(0).random((40, 40)), np.zeros((40, 40)), 7, 7, 3)
+        b.band_scan(np.zeros((40, 40), dtype=complex), np.zeros((40, 40)), 7, 7, 3)
     with pytest.raises(mods['n'].NativeError, match='exceeds 1024'):
         b.band_scan(np.zeros((80, 80), np.uint8), np.zeros((80, 80), np.uint8), 33, 32, 3)
     with pytest.raises(mods['n'].NativeError, match='does not fit the LDS tile'):
