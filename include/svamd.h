@@ -267,6 +267,9 @@ int svamd_band_scan_u8(const uint8_t *left, const uint8_t *right, int H, int W,
  * Images with NaN pixels are not supported.  Limits: win_w * win_h <= 4096,
  * stride_x == 1, the LDS tile as above.  Widths 25 and 31 have unrolled kernels. */
 size_t svamd_band_scan_f64_workspace_bytes(int H, int W, int win_w, int win_h);
+/* byte offset, inside that workspace, of an int32 that holds after a scan the number of
+ * windows that were evaluated again in float64 (a diagnostic) */
+size_t svamd_band_scan_f64_recheck_count_offset(int H, int W, int win_w, int win_h);
 int svamd_band_prepare_f64(const double *left, const double *right, int H, int W,
                            int win_w, int win_h, void *workspace, size_t workspace_bytes,
                            void *stream);

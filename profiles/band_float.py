@@ -50,13 +50,14 @@ def main():
         sc.upload(l, r)
         assert sc.kind == 'f64'
         prep = device_ms(sc.prepare)
-        for guard in (v.GUARD_BAND, 0.0):
+        for guard in (bs.BAND_GUARD_BAND, 0.0):
             v.SCAN_PRECISION = 'mixed' if guard else 'fp32'
             ms = device_ms(lambda: sc.run(0.5, prepared=True))
             out = dict(what=f'band scan {n}x{n}, float kernel, {tag}', guard_band=guard, prepare_ms=prep, scan_ms=ms,
                        tflops_float32_part=evals * 1922 / ms * 1e3 / 1e12)
             if guard:
-                # the second look's share: the list counter sits after the margins and the list in the workspace
+                out['windows_evaluated_again'] = sc.rechecked()
+                out['windows'] = int(sc.disp.numel())
                 out['disparities_equal_8bit_scan'] = bool(np.array_equal(sc.disp.cpu().numpy(), want)) \
                     if tag.startswith('8-bit') else None
             print(json.dumps(out), flush=True)

@@ -57,6 +57,7 @@ PROTOTYPES = {
     'svamd_band_scan_u8': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _d, _d, _i, _i, _i,
                                 _vp, _vp, _vp, _vp, _sz, _vp]),
     'svamd_band_scan_f64_workspace_bytes': (_sz, [_i, _i, _i, _i]),
+    'svamd_band_scan_f64_recheck_count_offset': (_sz, [_i, _i, _i, _i]),
     'svamd_band_prepare_f64': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     'svamd_band_scan_f64': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _d, _d, _d, _i, _i, _i,
                                  _vp, _vp, _vp, _vp, _sz, _vp]),

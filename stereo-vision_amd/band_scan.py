@@ -18,6 +18,12 @@ import _native as nv
 import sharding
 import sv_image_comparison as _svic
 
+# Floating-point images: decisions (comparisons of a score with the threshold or with
+# the best score so far) closer than this are repeated in float64.  The float32 scores
+# of the band kernel are products of centred pixels and stay within a few 1e-6 of the
+# float64 ones; evaluations that cannot promise that are sent to float64 regardless.
+BAND_GUARD_BAND = 1e-5
+
 WINDOW_WIDTHS = (7, 11, 15, 21, 25, 31)   # widths with a fully unrolled kernel; others take the run-time-width one
 
 
@@ -99,6 +105,15 @@ class BandScanner:
                 nv.ptr(self.right), h, w, self.win[0], self.win[1], nv.ptr(self.ws), self.ws.numel(),
                 nv.stream_ptr())
 
+    def rechecked(self):
+        '''Floating-point images: how many windows of the last run() were evaluated again in
+        float64 (0 for 8-bit images, whose first evaluation is exact).  Synchronises.'''
+        if self.kind == 'u8':
+            return 0
+        torch = nv.torch_cuda()
+        at = nv.load_library().svamd_band_scan_f64_recheck_count_offset(*self.shape, *self.win)
+        return int(self.ws[at:at + 4].view(torch.int32).item())
+
     def run(self, correlation_threshold=None, rows=None, prepared=False):
         '''Enqueues one scan on the current stream.  correlation_threshold None:
         plain arg-max per window; a number: image_scan's selection rule with that
@@ -114,7 +129,7 @@ class BandScanner:
             nv.call('svamd_band_scan_u8', *head, *tail)
         else:
             # float32 products; decisions within the scan's guard band are repeated in float64
-            guard = 0.0 if _svic.SCAN_PRECISION == 'fp32' else float(_svic.GUARD_BAND)
+            guard = 0.0 if _svic.SCAN_PRECISION == 'fp32' else float(BAND_GUARD_BAND)
             nv.call('svamd_band_scan_f64', *head, guard, *tail)
 
 

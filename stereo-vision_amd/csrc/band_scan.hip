@@ -820,9 +820,13 @@ band_collect_close_kernel(const double *__restrict__ margin, int nwx, int row_be
     list[atomicAdd(count, 1)] = (int32_t)(first + i);
 }
 
-// The windows on the list once more, every offset in float64 straight from the images
-// (one wavefront per window, a lane per offset), then the same selection.  The window
-// statistics are the tables' (they are float64 already); only the cross term differs.
+// The windows on the list once more, every offset in float64 straight from the images,
+// then the same selection.  One wavefront per window: the centred left window sits in
+// LDS, a lane owns OPL consecutive offsets and slides a ring of OPL right-image values
+// along each row (one load and one LDS read per OPL multiply-adds).  The window
+// statistics are the tables' (float64 already); only the cross term differs from the
+// first look.
+template <int OPL>
 __global__ void __launch_bounds__(WAVE)
 band_recheck_kernel(BandGeom g, const double *__restrict__ left, const double *__restrict__ right,
                     const Stats *__restrict__ image_stats, const double *__restrict__ wsum_l,
@@ -831,7 +835,9 @@ band_recheck_kernel(BandGeom g, const double *__restrict__ left, const double *_
                     const int32_t *__restrict__ count, int32_t *__restrict__ out_disp,
                     double *__restrict__ out_val, double *__restrict__ scores)
 {
-    extern __shared__ __align__(16) double sc[];
+    extern __shared__ __align__(16) double recheck_lds[];
+    double *Lw = recheck_lds;                         // win_h x win_w, centred
+    double *sc = recheck_lds + g.win_w * g.win_h;     // nd scores
     const int lane = threadIdx.x;
     const double centre_l = image_stats[0].mean, centre_r = image_stats[1].mean;
     const double n = (double)(g.win_w * g.win_h);
@@ -842,20 +848,53 @@ band_recheck_kernel(BandGeom g, const double *__restrict__ left, const double *_
         const int y = wy * g.stride_y;
         const int64_t srow = (int64_t)y * g.nsx;
         const double s1l = wsum_l[srow + wx], invl = winv_l[srow + wx];
-        __syncthreads();                       // the previous window's scores have been read
-        for (int k = lane; k < g.nd; k += WAVE) {
-            const int xr = wx + k - g.max_disp;
-            double s = NAN;
-            if (xr >= 0 && xr < g.nsx) {
-                double cross = 0.0;
-                for (int r = 0; r < g.win_h; ++r) {
-                    const double *lrow = left + (int64_t)(y + r) * g.W + wx;
-                    const double *rrow = right + (int64_t)(y + r) * g.W + xr;
-                    for (int c = 0; c < g.win_w; ++c)
-                        cross = fma(lrow[c] - centre_l, rrow[c] - centre_r, cross);
+        __syncthreads();                       // the previous window's LDS contents have been read
+        for (int i = lane; i < g.win_w * g.win_h; i += WAVE) {
+            const int r = i / g.win_w, c = i - r * g.win_w;
+            Lw[i] = left[(int64_t)(y + r) * g.W + wx + c] - centre_l;
+        }
+        __syncthreads();
+        const int k_first = lane * OPL;                       // this lane's first offset index
+        const int x_first = wx + k_first - g.max_disp;        // ... and its box's first column
+        double acc[OPL];
+#pragma unroll
+        for (int j = 0; j < OPL; ++j)
+            acc[j] = 0.0;
+        if (k_first < g.nd) {
+            for (int r = 0; r < g.win_h; ++r) {
+                const double *rrow = right + (int64_t)(y + r) * g.W;
+                const double *lrow = Lw + r * g.win_w;
+                // columns outside the image are read at the border: they only reach offsets
+                // whose box leaves the image, and those are discarded below
+                auto pixel = [&](int x) { return rrow[min(max(x, 0), g.W - 1)] - centre_r; };
+                double ring[OPL];                             // R[c + j] lives in slot (c + j) % OPL
+#pragma unroll
+                for (int j = 0; j + 1 < OPL; ++j)
+                    ring[j] = pixel(x_first + j);
+                for (int c0 = 0; c0 < g.win_w; c0 += OPL) {
+#pragma unroll
+                    for (int u = 0; u < OPL; ++u) {
+                        const int c = c0 + u;
+                        if (c < g.win_w) {                    // wave-uniform
+                            ring[(u + OPL - 1) % OPL] = pixel(x_first + c + OPL - 1);
+                            const double l = lrow[c];
+#pragma unroll
+                            for (int j = 0; j < OPL; ++j)
+                                acc[j] = fma(l, ring[(u + j) % OPL], acc[j]);
+                        }
+                    }
                 }
-                s = fma(n, cross, -(s1l * wsum_r[srow + xr])) * invl * winv_r[srow + xr];
             }
+        }
+#pragma unroll
+        for (int j = 0; j < OPL; ++j) {
+            const int k = k_first + j;
+            if (k >= g.nd)
+                continue;
+            const int xr = x_first + j;
+            double s = NAN;
+            if (xr >= 0 && xr < g.nsx)
+                s = fma(n, acc[j], -(s1l * wsum_r[srow + xr])) * invl * winv_r[srow + xr];
             sc[k] = s;
             if (scores)
                 scores[o * g.nd + k] = s;
@@ -1123,6 +1162,14 @@ extern "C" size_t svamd_band_scan_f64_workspace_bytes(int H, int W, int win_w, i
     return band_tables_f(nullptr, H, W, win_w, win_h).bytes;
 }
 
+extern "C" size_t svamd_band_scan_f64_recheck_count_offset(int H, int W, int win_w, int win_h)
+{
+    if (H <= 0 || W <= 0 || win_w <= 0 || win_h <= 0 || win_w > W || win_h > H)
+        return 0;
+    BandTablesF t = band_tables_f(nullptr, H, W, win_w, win_h);
+    return (size_t)(reinterpret_cast<char *>(t.count) - static_cast<char *>(nullptr));
+}
+
 extern "C" int svamd_band_prepare_f64(const double *left, const double *right, int H, int W, int win_w,
                                       int win_h, void *workspace, size_t workspace_bytes, void *stream)
 {
@@ -1225,8 +1272,27 @@ extern "C" int svamd_band_scan_f64(const double *left, const double *right, int 
                        g.nwx, row_begin, row_end, guard_band, t.list, t.count);
     SV_LAUNCH_CHECK();
     const unsigned rgrid = (unsigned)(total < 32768 ? total : 32768);
-    hipLaunchKernelGGL(band_recheck_kernel, dim3(rgrid), dim3(WAVE), (size_t)g.nd * sizeof(double), st, g, left, right,
-                       t.stats, t.wl, t.il, t.wr, t.ir, t.list, t.count, out_disp, out_val, scores);
+    const size_t rlds = ((size_t)win_w * win_h + g.nd) * sizeof(double);
+    const int opl = (g.nd + WAVE - 1) / WAVE;                 // offsets per lane of the second look
+    SV_REQUIRE(opl <= 8 && rlds <= 60 * 1024, SVAMD_ERR_LIMIT,
+               "band_scan_f64: %d offsets are more than the float64 second look handles (512)", g.nd);
+#define SV_RECHECK_CASE(N)                                                                                     \
+    case N:                                                                                                    \
+        hipLaunchKernelGGL(band_recheck_kernel<N>, dim3(rgrid), dim3(WAVE), rlds, st, g, left, right, t.stats, \
+                           t.wl, t.il, t.wr, t.ir, t.list, t.count, out_disp, out_val, scores);                \
+        break
+    switch (opl) {
+        SV_RECHECK_CASE(1);
+        SV_RECHECK_CASE(2);
+        SV_RECHECK_CASE(3);
+        SV_RECHECK_CASE(4);
+        SV_RECHECK_CASE(5);
+        SV_RECHECK_CASE(6);
+        SV_RECHECK_CASE(7);
+    default:
+        SV_RECHECK_CASE(8);
+    }
+#undef SV_RECHECK_CASE
     SV_LAUNCH_CHECK();
     return SVAMD_OK;
 }
