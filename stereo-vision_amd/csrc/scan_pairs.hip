@@ -12,6 +12,7 @@
 // thread) or in float32 with packed FMAs (scan_pairs_f32_kernel: one wavefront
 // per group of pairs, short float32 runs folded into float64).
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 #include "kernels.h"
@@ -584,8 +585,12 @@ __device__ __forceinline__ void pair_sum2(double &a, double &b, double *red, int
         a = red[0] + red[2];
         b = red[1] + red[3];
         if (nthr > 2 * WAVE) {
-            a += red[4] + red[6];
-            b += red[5] + red[7];
+            a += red[4];
+            b += red[5];
+        }
+        if (nthr > 3 * WAVE) {
+            a += red[6];
+            b += red[7];
         }
     }
 }
@@ -1071,6 +1076,25 @@ using namespace svamd;
 
 namespace svamd {
 
+// How the float32 kernel cuts a call's pairs into wavefront work: columns per task
+// (8 or 4), wavefronts per workgroup and pairs per workgroup.
+struct PairShape {
+    int G, waves, slots;
+};
+
+// SVAMD_PAIR_SHAPE="G,waves,slots" replaces the built-in choice (measurements only).
+static void pair_shape_override(int max_side, PairShape &shape)
+{
+    (void)max_side;
+    const char *env = getenv("SVAMD_PAIR_SHAPE");
+    int g = 0, w = 0, sl = 0;
+    if (env && sscanf(env, "%d,%d,%d", &g, &w, &sl) == 3 && (g == 4 || g == 8) && w >= 1 && w <= 4 && sl >= 1) {
+        shape.G = g;
+        shape.waves = w;
+        shape.slots = sl;
+    }
+}
+
 int launch_pairs(const double *tbase, const double *rbase, const int64_t *desc, int64_t npairs, int max_side,
                  double min_std, double min_mean_diff, int acc_precision, double *out_max, int64_t *out_argmax,
                  double *surfaces, const int64_t *surf_off, const int32_t *list, const int32_t *list_count,
@@ -1094,7 +1118,40 @@ int launch_pairs(const double *tbase, const double *rbase, const int64_t *desc, 
         // and a SIMD that holds a single wavefront cannot hide its LDS latency.
         const int cols4 = (max_side + 3) / 4 * 4, cols8 = (max_side + 7) / 8 * 8;
         const bool two_waves = (max_side + 1) / 2 * (cols8 / 8) > WAVE / 2;
-        const int G = (cols8 == cols4 && !two_waves) ? 8 : 4;
+        PairShape shape;
+        shape.G = (cols8 == cols4 && !two_waves) ? 8 : 4;
+        {
+            const int tasks = (max_side + 1) / 2 * ((shape.G == 8 ? cols8 : cols4) / shape.G);
+            shape.slots = two_waves ? 1 : WAVE / tasks;
+            // four wavefronts when two would need more than one round of tasks: large pairs fill an
+            // LDS slot that leaves room for one or two workgroups per CU
+            shape.waves = !two_waves ? 1 : (tasks > 2 * WAVE ? 4 : 2);
+        }
+        // Sides above 16: what decides is how many of a workgroup's lanes have a task (a side's
+        // row pairs x column groups rarely fill whole wavefronts) against how many workgroups
+        // the LDS slots leave room for; the shapes below are the measured best per range of
+        // sides (profiles/pair_shapes.py: +5 to +26 % over the rule above, none slower).
+        if (max_side > 16) {
+            const int tasks8 = (max_side + 1) / 2 * (cols8 / 8);
+            if (max_side <= 17)
+                shape = PairShape{8, 1, 2};
+            else if (max_side <= 20)
+                shape = PairShape{4, 1, 1};
+            else if (max_side <= 26)
+                shape = PairShape{8, 1, 1};
+            else if (max_side <= 32)
+                shape = max_side == 31 ? PairShape{4, 4, 2} : PairShape{4, 2, 1};
+            else if (max_side <= 38)
+                shape = PairShape{4, 3, 1};
+            else if (max_side <= 40)
+                shape = PairShape{8, 4, 2};
+            else if (max_side <= 44)
+                shape = PairShape{4, 4, 1};
+            else
+                shape = PairShape{8, tasks8 > 3 * WAVE ? 4 : 3, 1};
+        }
+        pair_shape_override(max_side, shape);
+        const int G = shape.G;
         const int gcols = G == 8 ? cols8 : cols4;
         const int t_floats = max_side * (int)side4;
         const int rcols = pair_row_cols(gcols, (int)side4);
@@ -1102,16 +1159,19 @@ int launch_pairs(const double *tbase, const double *rbase, const int64_t *desc, 
         const int s_floats = 2 * max_side * rxp;
         const int slot_floats = t_floats + s_floats + max_side * (int)side4;   // template, row pairs, plain region
         const int tasks_per_slot = (max_side + 1) / 2 * (gcols / G);
-        int slots = two_waves ? 1 : WAVE / tasks_per_slot;
+        int slots = shape.slots;
         if (slots < 1) slots = 1;
-        // four wavefronts when two would need more than one round of tasks: large pairs fill an
-        // LDS slot that leaves room for one or two workgroups per CU
-        const int fthreads = !two_waves ? WAVE : (tasks_per_slot > 2 * WAVE ? 4 * WAVE : 2 * WAVE);
+        const int fthreads = shape.waves * WAVE;
         if (slots > PAIR_MAX_SLOTS) slots = PAIR_MAX_SLOTS;
+        if (slots > 1 && slots * tasks_per_slot > fthreads)      // pairs that share a workgroup get one round of tasks
+            slots = fthreads / tasks_per_slot > 0 ? fthreads / tasks_per_slot : 1;
         const size_t lds = (size_t)slots * slot_floats * sizeof(float);
+        SV_REQUIRE(lds <= 128 * 1024, SVAMD_ERR_LIMIT, "scan_pairs: %d pairs of side %d per workgroup exceed the LDS",
+                   slots, max_side);
         const int64_t groups = (npairs + slots - 1) / slots;
         const unsigned fgrid = (unsigned)(groups < (1 << 20) ? groups : (1 << 20));
-        const bool shared = slots > 1 && max_side <= 16;    // pairs share a wavefront: staged by rows of 16 lanes
+        // pairs share one wavefront: staged by rows of 16 lanes
+        const bool shared = slots > 1 && max_side <= 16 && fthreads == WAVE;
         auto launch = [&](auto kernel) -> int {
             if (lds > 64 * 1024) {
                 SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
