@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-'''A/B timing of libsvamd builds on the batched 1024x1024 FFT correlation (batch
-64, float32 output), HIP events, interleaved rounds:
+'''A/B timing of libsvamd builds on the batched FFT correlation (AB_BATCH pairs, default
+64, of AB_H x AB_W, default 1024 x 1024; float32 output), HIP events, interleaved rounds:
 
     python3 profiles/ab_fft.py stereo-vision_amd/libsvamd.so /path/to/variant.so ...
 '''
@@ -26,12 +26,13 @@ def load(path):
 def main():
     paths = sys.argv[1:]
     libs = [load(p) for p in paths]
-    n, batch = 1024, int(os.environ.get('AB_BATCH', 64))
+    batch = int(os.environ.get('AB_BATCH', 64))
+    H, W = int(os.environ.get('AB_H', 1024)), int(os.environ.get('AB_W', 1024))
     g = torch.Generator(device='cuda').manual_seed(0)
-    t = torch.rand((batch, n, n), generator=g, device='cuda', dtype=torch.float32)
-    r = torch.rand((batch, n, n), generator=g, device='cuda', dtype=torch.float32)
-    out = torch.empty((batch, n, n), device='cuda', dtype=torch.float32)
-    ws = torch.empty(libs[0].svamd_xcorr2d_fft_workspace_bytes(batch, n, n), dtype=torch.uint8, device='cuda')
+    t = torch.rand((batch, H, W), generator=g, device='cuda', dtype=torch.float32)
+    r = torch.rand((batch, H, W), generator=g, device='cuda', dtype=torch.float32)
+    out = torch.empty((batch, H, W), device='cuda', dtype=torch.float32)
+    ws = torch.empty(libs[0].svamd_xcorr2d_fft_workspace_bytes(batch, H, W), dtype=torch.uint8, device='cuda')
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     # AB_FLUSH=1: a 1 GiB fill before every call pushes the buffers out of the 256 MB Infinity Cache
@@ -40,7 +41,7 @@ def main():
     def run(lib):
         if flush is not None:
             flush.fill_(1)
-        rc = lib.svamd_xcorr2d_fft(t.data_ptr(), n, n, r.data_ptr(), n, n, batch, 1e-4, 1e-9, out.data_ptr(), 1,
+        rc = lib.svamd_xcorr2d_fft(t.data_ptr(), H, W, r.data_ptr(), H, W, batch, 1e-4, 1e-9, out.data_ptr(), 1,
                                    ws.data_ptr(), ws.numel(), stream)
         assert rc == 0, lib.svamd_last_error()
 

@@ -732,12 +732,11 @@ hipError_t allow_lds(K kernel, size_t bytes)
                              : hipSuccess;
 }
 
-// workgroups take `steps` groups of rows each; more steps per workgroup keep the next
-// rows' loads in flight, as long as enough workgroups are left to fill the chip
-int wide_steps(int64_t total_steps)
-{
-    return total_steps >= 4 * 1024 ? 4 : total_steps >= 2 * 512 ? 2 : 1;
-}
+// Workgroups take two groups of rows each (the second group's loads are in flight while
+// the first is transformed) when that leaves enough workgroups to fill the chip; measured
+// on batches of 512 x 512 and 1024 x 1024 pairs and on single 2048 x 2048 pairs, where
+// one, two and four groups per workgroup lie within 5 % of each other.
+int wide_steps(int64_t total_steps, int64_t enough) { return total_steps >= enough ? 2 : 1; }
 
 template <int LOG2W>
 int wide_rows_forward(const float *tmpl, int th, int tw, const float *region, int H, int batch,
@@ -745,7 +744,7 @@ int wide_rows_forward(const float *tmpl, int th, int tw, const float *region, in
                       float2 *spec_r, int hp, int raw, hipStream_t st)
 {
     using R = WideRows<LOG2W>;
-    const int steps = wide_steps((int64_t)batch * (H / R::RG));
+    const int steps = wide_steps((int64_t)batch * (H / R::RG), 512);
     SV_HIP(allow_lds(&wide_rows_forward_kernel<LOG2W>, R::LDS_BYTES));
     hipLaunchKernelGGL(wide_rows_forward_kernel<LOG2W>, dim3(H / (R::RG * steps), batch), dim3(R::THREADS),
                        R::LDS_BYTES, st, tmpl, th, tw, region, H, stats, row_sums, table, spec_t, spec_r, hp,
@@ -774,7 +773,7 @@ int wide_rows_inverse(const float2 *spec, int th, int tw, int H, int hp, int bat
                       hipStream_t st)
 {
     using R = WideRows<LOG2W>;
-    const int steps = wide_steps((int64_t)batch * (H / (2 * R::RG)));
+    const int steps = wide_steps((int64_t)batch * (H / (2 * R::RG)), 1024);
     SV_HIP(allow_lds(&wide_rows_inverse_kernel<LOG2W, TOut>, R::LDS_BYTES));
     hipLaunchKernelGGL((wide_rows_inverse_kernel<LOG2W, TOut>), dim3(H / (2 * R::RG * steps), batch),
                        dim3(R::THREADS), R::LDS_BYTES, st, spec, th, tw, H, hp, stats, min_std, min_mean_diff,

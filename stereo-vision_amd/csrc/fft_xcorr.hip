@@ -14,6 +14,10 @@
 //                     output rows; scaling 1 / (H W std t * size t * std r) or the
 //                     constant surface of the low-deviation branch.
 //
+// The kernels of this file give every transform a whole workgroup, with a barrier per
+// stage; they serve the shapes with a side below 256.  When both sides are 256 ... 4096
+// the same three passes run with N / 16 threads per transform (fft_wide.hip).
+//
 // Transforms are radix-4 (one radix-2 stage when log2 N is odd), in place:
 // decimation in frequency forward (natural order in, digit-reversed out) and
 // decimation in time backward (digit-reversed in, natural out), so the pointwise
