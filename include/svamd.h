@@ -90,8 +90,9 @@ int svamd_cross_correlate_2d(const double *tmpl, int th, int tw,
  * globally normalised surface).  min_std / min_mean_diff are the module
  * constants MIN_ST_DEV / MIN_MEAN_DIFF (correlation_spectral.py:6,10).
  * Any shapes.  Evaluated directly (a sliding dot product over the wrapped region)
- * or, when that would take more than 2e10 products and the template (cropped to
- * the region) covers at least a quarter of the region, through FFTs of both
+ * or, when that is the slower way by the two routes' measured rates (from a few 1e9
+ * products) and the template (cropped to the region) covers at least a quarter of the
+ * region, through FFTs of both
  * operands zero-padded to powers of two (up to 4096 per side), which keeps the
  * circular semantics of the original shape exactly. */
 size_t svamd_cross_correlate_2d_spectral_workspace_bytes(int th, int tw, int rh, int rw);
@@ -125,7 +126,7 @@ int svamd_cross_correlate_1d(const double *v1, const double *v2, int64_t n, int 
 /* The same correlation for callers that cannot allocate or pass a workspace
  * (code under HIP graph capture, tight serving loops, harnesses that forbid
  * hipMalloc).  No counterpart in the reference.  The workspace is an array inside
- * the library's code object (about 19.7 MB per device, held until the process
+ * the library's code object (about 31 MB per device, held until the process
  * ends); the call allocates and frees nothing.  n is limited to
  * SVAMD_XCORR1D_STATIC_MAX_N samples (SVAMD_ERR_LIMIT beyond).  All calls on one
  * device share that array: calls that overlap in time on one device (different
@@ -142,7 +143,7 @@ int svamd_cross_correlate_1d_static(const double *v1, const double *v2, int64_t 
 /* ---- a5: cross_correlate_1d_spectral(template, signal) ------------------------
  * correlation_spectral.py:12-30.  out: ns + nt - 1 float64.  The shorter array
  * slides over the other (the circular correlation reads the same either way).
- * Above 2e10 products both 1D functions evaluate the sum through the library's 2D
+ * Above 2e9 products both 1D functions evaluate the sum through the library's 2D
  * float32 transforms (the arrays cut into rows: long recordings against snippets,
  * music_patterns_africa.py:24-45) as long as the two arrays together stay below
  * 8.3 million samples; the workspace size reflects the route. */

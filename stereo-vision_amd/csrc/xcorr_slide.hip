@@ -1238,10 +1238,12 @@ extern "C" int svamd_cross_correlate_2d(const double *tmpl, int th, int tw, cons
 // semantics kept exactly: see pad_operands_kernel) and costs O(P Q log(P Q)); its
 // float32 error is relative to |t| |r|, i.e. it grows like sqrt(region size /
 // template size) on the normalised surface, so it is taken only when the (cropped)
-// template covers at least a quarter of the region - and only when the sliding
-// kernel would need more than SPECTRAL_FFT_MIN_PRODUCTS products.
+// template covers at least a quarter of the region - and only when it is the faster
+// one by the two routes' measured rates: the sliding kernel evaluates about 4.5e10
+// products per millisecond, the transforms of a P x Q pair with the padding and the
+// epilogue take about 0.03 ms + 1.8e-8 ms per element (0.33 ms at 4096 x 4096).
 namespace {
-constexpr double SPECTRAL_FFT_MIN_PRODUCTS = 2e10;
+constexpr double SLIDE_MS_PER_PRODUCT = 2.2e-11, FFT_MS_FIXED = 0.03, FFT_MS_PER_ELEMENT = 1.8e-8;
 
 int next_pow2(int v)
 {
@@ -1269,8 +1271,8 @@ A2Route a2_route(int th, int tw, int rh, int rw)
     R.P = p2h ? rh : next_pow2(R.eh);
     R.Q = p2w ? rw : next_pow2(R.ew);
     const double products = (double)R.mh * R.mw * (double)rh * rw;
-    R.fft = products >= SPECTRAL_FFT_MIN_PRODUCTS && 4.0 * R.mh * R.mw >= (double)rh * rw &&
-            svamd_fft_supported(R.P, R.Q);
+    R.fft = products * SLIDE_MS_PER_PRODUCT > FFT_MS_FIXED + FFT_MS_PER_ELEMENT * (double)R.P * R.Q &&
+            4.0 * R.mh * R.mw >= (double)rh * rw && svamd_fft_supported(R.P, R.Q);
     return R;
 }
 }  // namespace
@@ -1367,7 +1369,7 @@ extern "C" int svamd_cross_correlate_2d_spectral(const void *tmpl, int tmpl_dtyp
 // float32 error is relative to |t| |e| and stays below 1e-5 of the result's scale for the
 // lengths this admits.
 namespace {
-constexpr double CORR1D_FFT_MIN_PRODUCTS = 2e10;
+constexpr double CORR1D_FFT_MIN_PRODUCTS = 2e9;
 struct Corr1dFft {
     bool ok;
     int Q, P, W;       // samples per row, rows and columns of the padded arrays
@@ -1517,7 +1519,8 @@ extern "C" int svamd_cross_correlate_1d(const double *v1, const double *v2, int6
 constexpr int64_t XCORR1D_STATIC_MAX_N = SVAMD_XCORR1D_STATIC_MAX_N;
 constexpr size_t XCORR1D_STATIC_BYTES = 2 * 256 + 2 * 512 * 8 /* statistics partials */ +
                                         (size_t)XCORR1D_STATIC_MAX_N * (4 + 12 + 24 + 4) /* operands, slack */ +
-                                        (size_t)16 * 2 * XCORR1D_STATIC_MAX_N * 8 /* partial sums */ + 8 * 256;
+                                        (size_t)16 * 2 * XCORR1D_STATIC_MAX_N * 8 /* partial sums */ + 8 * 256 +
+                                        ((size_t)11 << 20) /* padded arrays and spectra of the transform route */;
 static __device__ __align__(256) unsigned char xcorr1d_scratch[XCORR1D_STATIC_BYTES];
 
 namespace {

@@ -372,7 +372,7 @@ def test_1d_spectral_long_template_short_signal(mods, oracle):
 
 
 def test_1d_long_arrays_take_the_transform_route(mods):
-    '''Above 2e10 products the 1D correlations leave the sliding kernel for the 2D
+    '''Above 2e9 products the 1D correlations leave the sliding kernel for the 2D
     transforms (arrays cut into rows; raw[aQ + b] = C[a][b] + C[a + 1][b - Q]).  The
     full outputs against the reference's own formulas evaluated with numpy's float64
     FFTs (correlation_spectral.py:17-29; correlation.py:59-73 as a linear correlation
