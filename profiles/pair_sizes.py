@@ -13,7 +13,8 @@ rng = np.random.default_rng(4)
 H = W = 1024
 left = rng.random((H, W)); right = rng.random((H, W))
 dl, dr = nv.to_device(left), nv.to_device(right)
-for side in (8, 12, 16, 20, 24, 31, 32, 40, 48, 60, 64):
+SIDES = [int(a) for a in sys.argv[1:]] or [8, 12, 16, 20, 24, 25, 31, 32, 40, 48, 60, 64]
+for side in SIDES:
     n = max(1 << 14, min(1 << 20, int(2e11 / (2.0 * side ** 4))))
     ty = rng.integers(0, H - side, size=n); tx = rng.integers(0, W - side, size=n); rx = rng.integers(0, W - side, size=n)
     desc = np.empty((n, 8), dtype=np.int64)

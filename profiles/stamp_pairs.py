@@ -13,6 +13,8 @@ import sys
 import numpy as np
 import torch
 
+PHASES_MFMA = ['pixels arrived', 'statistics', 'staging', 'next requests issued', 'products', 'maximum',
+               'descriptor of the next pair', '-']
 PHASES = ['first pass: loads issued and summed', 'loads arrived, means reduced', 'deviations, LDS copies',
           'row-pair image', 'surfaces', 'maxima', 'descriptor read', 'template slot zeroed']
 
@@ -56,7 +58,8 @@ def main(path):
     stamps = (ctypes.c_ulonglong * 8)()
     lib.svamd_debug_pair_stamps(stamps, 0)
     total = sum(stamps)
-    for name, v in zip(PHASES, stamps):
+    names = PHASES_MFMA if side <= 32 and os.environ.get('SVAMD_PAIR_MFMA') != '0' else PHASES
+    for name, v in zip(names, stamps):
         print(f'{name:<32} {v / n:10.0f} clocks per pair  {100.0 * v / total:5.1f} %')
 
 

@@ -1037,6 +1037,260 @@ scan_pairs_f32_kernel(const double *__restrict__ tbase, const double *__restrict
 #endif
 }
 
+// ---- float32 multiply-accumulate on the matrix cores: one wavefront per pair -------------
+// The surface of a pair is a matrix product: with m' = (m + k) mod rh,
+//     c[k][l] = sum_{m', n} A[k][(m', n)] * B[(m', n)][l],
+//     A[k][(m', n)] = t'[(m' - k) mod rh][n]   (t' zero beyond its mh x mw values),
+//     B[(m', n)][l] = r'[m'][(n + l) mod rw],
+// i.e. rh * mw steps of rank 1, the same products as the direct sum and no others.  One
+// v_mfma_f32_32x32x2_f32 covers two steps for a 32 x 32 tile of (k, l): it replaces 32
+// vector FMAs per lane by one instruction and two 4-byte LDS reads, and float32 matrix and
+// vector instructions have the same peak rate.  Operand addresses are a per-lane base plus
+// the step's offset: lane k reads template row m' - k, or m' - k + rh for the rows before
+// its own (one select per row of 16 instructions), and the region is staged wrapped
+// horizontally to nloop + 32 columns (lane l reads column n + l).  Partial sums stay in
+// float32 for at most 256 products (four accumulator tiles, each for a quarter of the rows)
+// and are added in float64.  Sides up to 32.
+typedef float pm16 __attribute__((ext_vector_type(16)));
+constexpr int PM_SIDE = 32;
+constexpr int PM_TP = 33;                 // template row pitch: the 32 rows of an A read on 32 banks
+constexpr int PM_TROWS = PM_SIDE;
+constexpr int PM_RP = 2 * PM_SIDE;        // region row pitch
+constexpr int PM_SLOT_FLOATS = PM_TROWS * PM_TP + PM_SIDE * PM_RP + 8;   // + the reach of the reads requested ahead
+constexpr int PM_WAVES = 4;               // independent wavefronts (pairs) per workgroup
+constexpr int PM_MIN_SIDE = 0;            // smaller pairs keep the kernel in which several share a wavefront
+
+__global__ void __launch_bounds__(PM_WAVES * WAVE, 3)
+scan_pairs_mfma_kernel(const double *__restrict__ tbase, const double *__restrict__ rbase,
+                       const PairDesc *__restrict__ desc, int64_t npairs, int max_side, double min_std,
+                       double min_mean_diff, double *__restrict__ out_max, int64_t *__restrict__ out_argmax,
+                       double *__restrict__ surfaces, const int64_t *__restrict__ surf_off)
+{
+    __shared__ float slots[PM_WAVES * PM_SLOT_FLOATS];
+    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+    float *Tt = slots + wave * PM_SLOT_FLOATS, *Rr = Tt + PM_TROWS * PM_TP;
+    const int lx = lane & 31, ly = lane >> 5;
+    const int64_t first = (int64_t)blockIdx.x * PM_WAVES + wave, stride = (int64_t)gridDim.x * PM_WAVES;
+
+    // A lane keeps column lx, rows ly, ly + 2, ... of both boxes.  Loads are not predicated: a
+    // lane beyond the box reads the box's last row / column again and its value is masked
+    // where it is used.  (Nothing is requested a pair ahead: the 64 registers that would
+    // hold cost the third wavefront per SIMD, and with three wavefronts two compute while
+    // one waits.)
+    double tk[PM_SIDE / 2], rk[PM_SIDE / 2];
+    auto request = [&](const PairDesc &d, bool ok) {
+        const int th = (int)d.t_h, tw = (int)d.t_w, rh = (int)d.r_h, rw = (int)d.r_w;
+        if (ok && th > 0 && tw > 0) {
+            const double *T = tbase + d.t_off;
+            const unsigned pitch = (unsigned)d.t_pitch, cx = (unsigned)min(lx, tw - 1);
+#pragma unroll
+            for (int j = 0; j < PM_SIDE / 2; ++j)
+                tk[j] = T[(unsigned)min(ly + 2 * j, th - 1) * pitch + cx];
+        } else {
+#pragma unroll
+            for (int j = 0; j < PM_SIDE / 2; ++j)
+                tk[j] = 0.0;
+        }
+        if (ok) {
+            const double *R = rbase + d.r_off;
+            const unsigned pitch = (unsigned)d.r_pitch, cx = (unsigned)min(lx, rw - 1);
+#pragma unroll
+            for (int j = 0; j < PM_SIDE / 2; ++j)
+                rk[j] = R[(unsigned)min(ly + 2 * j, rh - 1) * pitch + cx];
+        } else {
+#pragma unroll
+            for (int j = 0; j < PM_SIDE / 2; ++j)
+                rk[j] = 0.0;
+        }
+    };
+#ifdef SV_PAIR_STAMPS
+    unsigned long long stamp_acc_[8] = {};
+    unsigned long long stamp_ = clock64();
+#endif
+    // Descriptors travel two pairs ahead, one 8-byte word per lane (a scalar load would be
+    // waited for at the next LDS operation: they share a counter).
+    auto desc_word = [&](int64_t q) -> int64_t {
+        return q < npairs ? reinterpret_cast<const int64_t *>(desc + q)[lane & 7] : (int64_t)0;
+    };
+    auto unpack = [&](int64_t w) {
+        auto word = [&](int i) -> int64_t {
+            const int lo = __builtin_amdgcn_readlane((int)(w & 0xffffffff), i);
+            const int hi = __builtin_amdgcn_readlane((int)(w >> 32), i);
+            return ((int64_t)hi << 32) | (uint32_t)lo;
+        };
+        PairDesc d;
+        d.t_off = word(0);
+        d.t_pitch = word(1);
+        d.t_h = word(2);
+        d.t_w = word(3);
+        d.r_off = word(4);
+        d.r_pitch = word(5);
+        d.r_h = word(6);
+        d.r_w = word(7);
+        return d;
+    };
+    PairDesc d_next = unpack(desc_word(first));
+    bool ok_next = first < npairs && pair_desc_ok(d_next, max_side) && max_side <= PM_SIDE;
+    int64_t w_after = desc_word(first + stride);
+    for (int64_t p = first; p < npairs; p += stride) {
+        const PairDesc d = d_next;
+        const bool ok = ok_next;
+        request(d, ok);
+        d_next = unpack(w_after);
+        ok_next = p + stride < npairs && pair_desc_ok(d_next, max_side) && max_side <= PM_SIDE;
+        w_after = desc_word(p + 2 * stride);
+        if (!ok) {
+            if (lane == 0) {
+                out_max[p] = NAN;
+                if (out_argmax)
+                    out_argmax[p] = -1;
+            }
+            continue;
+        }
+        const int th = (int)d.t_h, tw = (int)d.t_w, rh = (int)d.r_h, rw = (int)d.r_w;
+        const int tn = th * tw, rn = rh * rw;
+        const int mh = min(th, rh), mw = min(tw, rw);
+        const int nloop = (mw + 3) & ~3;
+        PAIR_STAMP(6);          // descriptor of the next pair
+        double ts = 0.0, rs = 0.0;
+#pragma unroll
+        for (int j = 0; j < PM_SIDE / 2; ++j) {
+            const int y = ly + 2 * j;
+            tk[j] = (lx < tw && y < th) ? tk[j] : 0.0;
+            rk[j] = (lx < rw && y < rh) ? rk[j] : 0.0;
+            ts += tk[j];
+            rs += rk[j];
+        }
+        PAIR_STAMP(0);          // pixels arrived
+        const double tmean = wave_sum(ts) / (double)tn, rmean = wave_sum(rs) / (double)rn;
+        double tq = 0.0, rq = 0.0;
+#pragma unroll
+        for (int j = 0; j < PM_SIDE / 2; ++j) {
+            const int y = ly + 2 * j;
+            tk[j] = (lx < tw && y < th) ? tk[j] - tmean : 0.0;
+            rk[j] = (lx < rw && y < rh) ? rk[j] - rmean : 0.0;
+            tq = fma(tk[j], tk[j], tq);
+            rq = fma(rk[j], rk[j], rq);
+        }
+        const double tstd = sqrt(wave_sum(tq) / (double)tn), rstd = sqrt(wave_sum(rq) / (double)rn);
+        PAIR_STAMP(1);          // statistics
+        double *surf = surfaces ? surfaces + surf_off[p] : nullptr;
+        if (tstd < min_std) {      // homogeneous template: constant surface
+            const double fill = fabs(tmean - rmean) < min_mean_diff ? 1.0 : 0.0;
+            if (surf)
+                for (int i = lane; i < rn; i += WAVE)
+                    surf[i] = fill;
+            if (lane == 0) {
+                out_max[p] = fill;
+                if (out_argmax)
+                    out_argmax[p] = 0;
+            }
+            continue;
+        }
+        // An empty template transforms to an all-zero spectrum: the surface is 0 wherever
+        // the normalised region is finite.
+        const double scale = tn == 0 ? ((rstd > 0.0) ? 0.0 : NAN) : 1.0 / (tstd * (double)tn) / rstd;
+
+        // ---- staging (this wavefront's LDS operations complete in order) ----
+        __builtin_amdgcn_wave_barrier();
+        {
+            // column x of the wrapped region image holds column x mod rw: fetched from the lane
+            // that keeps it (same row parity), so that no write needs a predicate
+            const int src0 = 4 * ((lx % rw) + 32 * ly), src1 = 4 * (((lx + 32) % rw) + 32 * ly);
+            float *tcol = Tt + lx, *rcol = Rr + lx;
+#pragma unroll
+            for (int j = 0; j < PM_SIDE / 2; ++j) {
+                const int y = ly + 2 * j;
+                // zeros beyond the template's own rows and columns (the 32 lanes of a row cover
+                // every column a step reads, the 32 rows every row)
+                tcol[y * PM_TP] = (y < mh && lx < mw) ? (float)tk[j] : 0.0f;
+                const int rv = __float_as_int((float)rk[j]);
+                rcol[y * PM_RP] = __int_as_float(__builtin_amdgcn_ds_bpermute(src0, rv));
+                rcol[y * PM_RP + PM_SIDE] = __int_as_float(__builtin_amdgcn_ds_bpermute(src1, rv));
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        PAIR_STAMP(2);          // staging
+
+        // ---- the surface ----
+        pm16 acc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int v = 0; v < 16; ++v)
+                acc[q][v] = 0.0f;
+        if (tn != 0) {
+            // lanes beyond the surface's rows repeat its last row (their results are dropped)
+            const int kk = min(lx, rh - 1);
+            const float *pa_lo = Tt - kk * PM_TP + ly, *pa_hi = pa_lo + rh * PM_TP;   // + m' * PM_TP + n
+            const float *pb = Rr + lx + ly;                                          // + m' * PM_RP + n
+            const int rows_q = (rh + 3) / 4;
+            const int chunks = nloop / 4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int m_end = min((q + 1) * rows_q, rh);
+                for (int m = q * rows_q; m < m_end; ++m) {
+                    const float *ra = (m >= kk ? pa_lo : pa_hi) + m * PM_TP, *rb = pb + m * PM_RP;
+                    float a0 = ra[0], a1 = ra[2], b0 = rb[0], b1 = rb[2];
+                    for (int c = 0; c < chunks; ++c) {
+                        // the next chunk's operands are requested before this chunk's products
+                        // (past the row's end they are read and dropped: still inside the slot)
+                        const float na0 = ra[4 * c + 4], na1 = ra[4 * c + 6];
+                        const float nb0 = rb[4 * c + 4], nb1 = rb[4 * c + 6];
+                        acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[q], 0, 0, 0);
+                        acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[q], 0, 0, 0);
+                        a0 = na0;
+                        a1 = na1;
+                        b0 = nb0;
+                        b1 = nb1;
+                    }
+                }
+            }
+        }
+        PAIR_STAMP(4);          // products
+        // element v of a lane: row 8 (v / 4) + 4 (lane / 32) + v % 4, column lane % 32; a lane's
+        // indices ascend with v, so its first maximum is the one a strict comparison keeps
+        BestNan mine;
+        mine.best = -INFINITY;
+        mine.arg = 0x7fffffff;
+        mine.has_nan = 0;
+        const int idx0 = 4 * ly * rw + lx;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int k0 = 8 * (v / 4) + (v % 4);            // + 4 ly
+            const bool valid = k0 + 4 * ly < rh && lx < rw;
+            const double sum = ((double)acc[0][v] + (double)acc[1][v]) + ((double)acc[2][v] + (double)acc[3][v]);
+            const double val = tn == 0 ? scale : sum * scale;
+            const int idx = idx0 + k0 * rw;
+            mine.has_nan |= (valid && isnan(val)) ? 1 : 0;
+            const bool better = valid && val > mine.best;
+            mine.best = better ? val : mine.best;
+            mine.arg = better ? idx : mine.arg;
+        }
+        if (surf) {             // the whole surface is wanted: rare, kept out of the loop above
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int k0 = 8 * (v / 4) + (v % 4);
+                const double sum = ((double)acc[0][v] + (double)acc[1][v]) + ((double)acc[2][v] + (double)acc[3][v]);
+                if (k0 + 4 * ly < rh && lx < rw)
+                    surf[idx0 + k0 * rw] = tn == 0 ? scale : sum * scale;
+            }
+        }
+        mine = wave_best(mine);
+        if (lane == 0) {
+            out_max[p] = mine.has_nan ? NAN : mine.best;
+            if (out_argmax)
+                out_argmax[p] = mine.arg == 0x7fffffff ? -1 : mine.arg;
+        }
+        PAIR_STAMP(5);          // maximum
+    }
+#ifdef SV_PAIR_STAMPS
+    if (lane == 0)
+        for (int i = 0; i < 8; ++i)
+            atomicAdd(&pair_stamps[i], stamp_acc_[i]);
+#endif
+}
+
 // image_scan's sequential selection rule, one thread per window.
 __global__ void __launch_bounds__(256)
 scan_fold_kernel(const double *__restrict__ corr_max, const uint8_t *__restrict__ is_centre,
@@ -1111,6 +1365,17 @@ int launch_pairs(const double *tbase, const double *rbase, const int64_t *desc, 
     const int tasks = max_side * ((max_side + w64 - 1) / w64);
     const int threads = tasks <= 64 ? 64 : tasks <= 128 ? 128 : 256;
     const unsigned grid = list ? list_grid : (unsigned)(npairs < (1 << 20) ? npairs : (1 << 20));
+    // SVAMD_PAIR_MFMA=0 keeps the vector-ALU kernel for sides up to 32 (measurements only)
+    static const bool mfma_off = getenv("SVAMD_PAIR_MFMA") && atoi(getenv("SVAMD_PAIR_MFMA")) == 0;
+    if (acc_precision == SVAMD_ACC_F32 && max_side <= PM_SIDE && max_side > PM_MIN_SIDE && !mfma_off) {
+        // one wavefront per pair on the matrix cores; three workgroups of four wavefronts fit a CU
+        const int64_t groups = (npairs + PM_WAVES - 1) / PM_WAVES;
+        const unsigned mgrid = (unsigned)(groups < 256 * 3 ? groups : 256 * 3);
+        hipLaunchKernelGGL(scan_pairs_mfma_kernel, dim3(mgrid), dim3(PM_WAVES * WAVE), 0, st, tbase, rbase, pd, npairs,
+                           max_side, min_std, min_mean_diff, out_max, out_argmax, surfaces, surf_off);
+        SV_LAUNCH_CHECK();
+        return SVAMD_OK;
+    }
     if (acc_precision == SVAMD_ACC_F32) {
         // columns per task: 8 unless 4 wastes fewer padded columns
         // Pairs with more than 32 tasks of 8 columns get a workgroup of two wavefronts
