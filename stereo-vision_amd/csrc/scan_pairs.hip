@@ -1291,6 +1291,269 @@ scan_pairs_mfma_kernel(const double *__restrict__ tbase, const double *__restric
 #endif
 }
 
+// Sides up to 16: four pairs per wavefront, one per row of 16 lanes, on the four-block
+// instruction v_mfma_f32_16x16x1_f32 (block b multiplies pair b's operands: one rank-1 step
+// of a 16 x 16 tile per instruction).  Staging as above with a lane owning one column of
+// its pair's template and region (16 rows in registers); sums run down the column and
+// across the row of 16 lanes.  The four pairs walk the largest row and column counts among
+// them; what a smaller pair reads beyond its own is a zero of its template or region
+// image.  At most 256 products per surface element: one float32 accumulator.
+constexpr int PS_SIDE = 16;
+constexpr int PS_TP = 17;                 // template row pitch
+constexpr int PS_RP = 2 * PS_SIDE;        // region row pitch (wrapped to nloop + 16 columns)
+constexpr int PS_WAVES = 4;
+
+// ROWS: the largest side of the call (8, 12 or 16): rows a lane keeps, rows of the LDS
+// images - smaller pairs cost fewer instructions and leave room for more wavefronts.
+template <int ROWS>
+__global__ void __launch_bounds__(PS_WAVES * WAVE, ROWS <= 12 ? 4 : 3)
+scan_pairs_mfma16_kernel(const double *__restrict__ tbase, const double *__restrict__ rbase,
+                         const PairDesc *__restrict__ desc, int64_t npairs, int max_side, double min_std,
+                         double min_mean_diff, double *__restrict__ out_max, int64_t *__restrict__ out_argmax,
+                         double *__restrict__ surfaces, const int64_t *__restrict__ surf_off)
+{
+    constexpr int PS_PAIR_FLOATS = ROWS * PS_TP + ROWS * PS_RP;
+    constexpr int PS_SLOT_FLOATS = 4 * PS_PAIR_FLOATS + 8;               // a wavefront's four pairs
+    __shared__ float slots[PS_WAVES * PS_SLOT_FLOATS];
+    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+    const int x = lane & 15, g = lane >> 4;
+    float *Tt = slots + wave * PS_SLOT_FLOATS + g * PS_PAIR_FLOATS, *Rr = Tt + ROWS * PS_TP;
+    const int64_t first = ((int64_t)blockIdx.x * PS_WAVES + wave) * 4, stride = (int64_t)gridDim.x * PS_WAVES * 4;
+
+    // descriptors are read one round ahead (every lane of a row its pair's)
+    auto read_desc = [&](int64_t q) {
+        PairDesc d;
+        d.t_off = d.r_off = d.t_pitch = d.r_pitch = 0;
+        d.t_h = d.t_w = d.r_h = d.r_w = 0;
+        if (q < npairs)
+            d = desc[q];
+        return d;
+    };
+    PairDesc d_next = read_desc(first + g);
+    for (int64_t base = first; base < npairs; base += stride) {
+        const int64_t p = base + g;
+        const bool present = p < npairs;
+        const PairDesc d = d_next;
+        d_next = read_desc(p + stride);
+        const bool ok = present && pair_desc_ok(d, max_side) && max_side <= ROWS;
+        const int th = ok ? (int)d.t_h : 0, tw = ok ? (int)d.t_w : 0;
+        const int rh = ok ? (int)d.r_h : 0, rw = ok ? (int)d.r_w : 0;
+        // ---- statistics: lane x keeps column x of its pair's boxes; loads are not predicated
+        // (a lane beyond the box reads its last row / column again; masked below) ----
+        double tc[ROWS], rc[ROWS];
+        {
+            const bool tl = th > 0 && tw > 0, rl = rh > 0 && rw > 0;
+            const double *T = tbase + (tl ? d.t_off : 0), *R = rbase + (rl ? d.r_off : 0);
+            const unsigned tp = tl ? (unsigned)d.t_pitch : 0u, rp = rl ? (unsigned)d.r_pitch : 0u;
+            const unsigned tx = tl ? (unsigned)min(x, tw - 1) : 0u, rx = rl ? (unsigned)min(x, rw - 1) : 0u;
+#pragma unroll
+            for (int y = 0; y < ROWS; ++y) {
+                tc[y] = T[(unsigned)min(y, max(th - 1, 0)) * tp + tx];
+                rc[y] = R[(unsigned)min(y, max(rh - 1, 0)) * rp + rx];
+            }
+        }
+        double ts = 0.0, rs = 0.0;
+#pragma unroll
+        for (int y = 0; y < ROWS; ++y) {
+            tc[y] = (x < tw && y < th) ? tc[y] : 0.0;
+            rc[y] = (x < rw && y < rh) ? rc[y] : 0.0;
+            ts += tc[y];
+            rs += rc[y];
+        }
+        const double tn = (double)(th * tw), rn = (double)(rh * rw);
+        const double tmean = row16_sum(ts) / tn, rmean = row16_sum(rs) / rn;
+        double tq = 0.0, rq = 0.0;
+#pragma unroll
+        for (int y = 0; y < ROWS; ++y) {
+            tc[y] = (x < tw && y < th) ? tc[y] - tmean : 0.0;
+            rc[y] = (x < rw && y < rh) ? rc[y] - rmean : 0.0;
+            tq = fma(tc[y], tc[y], tq);
+            rq = fma(rc[y], rc[y], rq);
+        }
+        const double tstd = sqrt(row16_sum(tq) / tn), rstd = sqrt(row16_sum(rq) / rn);
+        const bool flat = ok && tstd < min_std;
+        const bool evaluate = ok && !flat;
+        const int mh = min(th, rh), mw = min(tw, rw);
+        const int nloop = evaluate ? (mw + 3) & ~3 : 0;
+        // An empty template transforms to an all-zero spectrum: the surface is 0 wherever
+        // the normalised region is finite.
+        const double scale = th * tw == 0 ? ((rstd > 0.0) ? 0.0 : NAN) : 1.0 / (tstd * tn) / rstd;
+
+        // ---- staging (this wavefront's LDS operations complete in order).  A pair that is
+        // not evaluated stages zeros: its lanes walk the other pairs' steps. ----
+        __builtin_amdgcn_wave_barrier();
+        {
+            const int rwc = max(rw, 1);
+            const int src0 = 4 * (16 * g + x % rwc), src1 = 4 * (16 * g + (x + 16) % rwc);
+#pragma unroll
+            for (int y = 0; y < ROWS; ++y) {
+                Tt[y * PS_TP + x] = (evaluate && y < mh && x < mw) ? (float)tc[y] : 0.0f;
+                const int rv = __float_as_int(evaluate ? (float)rc[y] : 0.0f);
+                Rr[y * PS_RP + x] = __int_as_float(__builtin_amdgcn_ds_bpermute(src0, rv));
+                Rr[y * PS_RP + x + 16] = __int_as_float(__builtin_amdgcn_ds_bpermute(src1, rv));
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- the surfaces: the step counts of the largest pair in the wavefront ----
+        int u_rows = evaluate ? rh : 0, u_cols = nloop;
+        u_rows = max(max(__builtin_amdgcn_readlane(u_rows, 0), __builtin_amdgcn_readlane(u_rows, 16)),
+                     max(__builtin_amdgcn_readlane(u_rows, 32), __builtin_amdgcn_readlane(u_rows, 48)));
+        u_cols = max(max(__builtin_amdgcn_readlane(u_cols, 0), __builtin_amdgcn_readlane(u_cols, 16)),
+                     max(__builtin_amdgcn_readlane(u_cols, 32), __builtin_amdgcn_readlane(u_cols, 48)));
+        // two accumulators take turns, so that an instruction does not wait for the one before it
+        pm16 acc, acc_b;
+#pragma unroll
+        for (int v = 0; v < 16; ++v)
+            acc[v] = acc_b[v] = 0.0f;
+        {
+            // lane (g, k) reads template row m' - k, or m' - k + rh for the rows before its own;
+            // lanes beyond the surface's rows repeat its last row (their results are dropped)
+            const int rhc = max(rh, 1), kk = min(x, rhc - 1);
+            const float *pa_lo = Tt - kk * PS_TP, *pa_hi = pa_lo + rhc * PS_TP;
+            const float *pb = Rr + x;
+            for (int m = 0; m < u_rows; ++m) {
+                // rows from rh on (a smaller pair): the region image holds zeros there and any
+                // template row will do - the select below stays inside the image
+                const float *ra = (m >= kk ? pa_lo : pa_hi) + min(m, rhc - 1 + kk) * PS_TP, *rb = pb + m * PS_RP;
+                for (int n = 0; n < u_cols; n += 4) {
+                    const float a0 = ra[n], a1 = ra[n + 1], a2 = ra[n + 2], a3 = ra[n + 3];
+                    const float b0 = rb[n], b1 = rb[n + 1], b2 = rb[n + 2], b3 = rb[n + 3];
+                    acc = __builtin_amdgcn_mfma_f32_16x16x1f32(a0, b0, acc, 0, 0, 0);
+                    acc_b = __builtin_amdgcn_mfma_f32_16x16x1f32(a1, b1, acc_b, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x1f32(a2, b2, acc, 0, 0, 0);
+                    acc_b = __builtin_amdgcn_mfma_f32_16x16x1f32(a3, b3, acc_b, 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < 16; ++v)
+            acc[v] += acc_b[v];
+        // ---- results: element v of a lane belongs to pair v / 4, row 4 (lane / 16) + v % 4,
+        // column lane % 16.  The raw sums are compared (a pair's scale is positive and the
+        // same for all its elements; distinct float32 sums stay distinct in float64), first
+        // inside the lane, then across the lanes in a way that ends with pair b's result in
+        // row b of the lanes - the row that holds the pair's shape, scale and state. ----
+        float bv[4];
+        int bi[4], bn[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int brh = __builtin_amdgcn_readlane(rh, 16 * b), brw = __builtin_amdgcn_readlane(rw, 16 * b);
+            bv[b] = -INFINITY;
+            bi[b] = 0x7fffffff;
+            bn[b] = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = 4 * g + e;
+                const bool valid = k < brh && x < brw;
+                const float val = acc[4 * b + e];
+                bn[b] |= (valid && isnan(val)) ? 1 : 0;
+                const bool better = valid && val > bv[b];       // ascending index inside the lane
+                bv[b] = better ? val : bv[b];
+                bi[b] = better ? k * brw + x : bi[b];
+            }
+        }
+        auto merge = [](float &v, int &i, int &n, float ov, int oi, int on) {
+            const bool take = ov > v || (ov == v && oi < i);
+            v = take ? ov : v;
+            i = take ? oi : i;
+            n |= on;
+        };
+        {
+            // lanes 32 apart: the lower half keeps pairs 0 and 1, the upper half pairs 2 and 3
+            const bool upper = lane >= 32;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float sv = upper ? bv[h] : bv[h + 2];
+                const int si = upper ? bi[h] : bi[h + 2], sn = upper ? bn[h] : bn[h + 2];
+                const float ov = __shfl_xor(sv, 32, WAVE);
+                const int oi = __shfl_xor(si, 32, WAVE), on = __shfl_xor(sn, 32, WAVE);
+                float &kv = bv[h];
+                if (upper) {
+                    bv[h] = bv[h + 2];
+                    bi[h] = bi[h + 2];
+                    bn[h] = bn[h + 2];
+                }
+                merge(kv, bi[h], bn[h], ov, oi, on);
+            }
+            // lanes 16 apart: even rows keep the first of their two pairs, odd rows the second
+            const bool odd = (g & 1) != 0;
+            const float sv = odd ? bv[0] : bv[1];
+            const int si = odd ? bi[0] : bi[1], sn = odd ? bn[0] : bn[1];
+            const float ov = __shfl_xor(sv, 16, WAVE);
+            const int oi = __shfl_xor(si, 16, WAVE), on = __shfl_xor(sn, 16, WAVE);
+            if (odd) {
+                bv[0] = bv[1];
+                bi[0] = bi[1];
+                bn[0] = bn[1];
+            }
+            merge(bv[0], bi[0], bn[0], ov, oi, on);
+        }
+        // across the 16 lanes of the row (every lane ends with the row's best)
+        {
+            float v = bv[0];
+            int i = bi[0], n = bn[0];
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1)
+                merge(v, i, n, __shfl_xor(v, o, WAVE), __shfl_xor(i, o, WAVE), __shfl_xor(n, o, WAVE));
+            bv[0] = v;
+            bi[0] = i;
+            bn[0] = n;
+        }
+        if (present && x == 0) {
+            double result;
+            int64_t arg;
+            if (!ok) {
+                result = NAN;
+                arg = -1;
+            } else if (flat) {
+                result = fabs(tmean - rmean) < min_mean_diff ? 1.0 : 0.0;
+                arg = 0;
+            } else {
+                // a constant region (scale infinite or NaN): every element is 0 / 0
+                const bool all_nan = !isfinite(scale);
+                const double val = th * tw == 0 ? scale : (double)bv[0] * scale;
+                result = (bn[0] || all_nan) ? NAN : val;
+                arg = (all_nan || bi[0] == 0x7fffffff) ? -1 : bi[0];
+            }
+            out_max[p] = result;
+            if (out_argmax)
+                out_argmax[p] = arg;
+        }
+        if (surfaces) {          // the whole surfaces are wanted: rare
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                if (base + b >= npairs)
+                    continue;
+                const int state = __builtin_amdgcn_readlane(!ok ? 2 : flat ? 1 : 0, 16 * b);
+                if (state == 2)
+                    continue;
+                const int brh = __builtin_amdgcn_readlane(rh, 16 * b), brw = __builtin_amdgcn_readlane(rw, 16 * b);
+                double *surf = surfaces + surf_off[base + b];
+                if (state == 1) {
+                    const double tm = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(tmean), 16 * b),
+                                                       __builtin_amdgcn_readlane(__double2loint(tmean), 16 * b));
+                    const double rm = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(rmean), 16 * b),
+                                                       __builtin_amdgcn_readlane(__double2loint(rmean), 16 * b));
+                    const double fill = fabs(tm - rm) < min_mean_diff ? 1.0 : 0.0;
+                    for (int i = lane; i < brh * brw; i += WAVE)
+                        surf[i] = fill;
+                    continue;
+                }
+                const double bscale = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(scale), 16 * b),
+                                                       __builtin_amdgcn_readlane(__double2loint(scale), 16 * b));
+                const bool empty = __builtin_amdgcn_readlane(th * tw, 16 * b) == 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int k = 4 * g + e;
+                    if (k < brh && x < brw)
+                        surf[k * brw + x] = empty ? bscale : (double)acc[4 * b + e] * bscale;
+                }
+            }
+        }
+    }
+}
+
 // image_scan's sequential selection rule, one thread per window.
 __global__ void __launch_bounds__(256)
 scan_fold_kernel(const double *__restrict__ corr_max, const uint8_t *__restrict__ is_centre,
@@ -1367,6 +1630,22 @@ int launch_pairs(const double *tbase, const double *rbase, const int64_t *desc, 
     const unsigned grid = list ? list_grid : (unsigned)(npairs < (1 << 20) ? npairs : (1 << 20));
     // SVAMD_PAIR_MFMA=0 keeps the vector-ALU kernel for sides up to 32 (measurements only)
     static const bool mfma_off = getenv("SVAMD_PAIR_MFMA") && atoi(getenv("SVAMD_PAIR_MFMA")) == 0;
+    if (acc_precision == SVAMD_ACC_F32 && max_side <= PS_SIDE && !mfma_off) {
+        // four pairs per wavefront on the matrix cores
+        const int64_t groups = (npairs + 4 * PS_WAVES - 1) / (4 * PS_WAVES);
+        const unsigned mgrid = (unsigned)(groups < 256 * 4 ? groups : 256 * 4);
+        if (max_side <= 8)
+            hipLaunchKernelGGL(scan_pairs_mfma16_kernel<8>, dim3(mgrid), dim3(PS_WAVES * WAVE), 0, st, tbase, rbase, pd,
+                               npairs, max_side, min_std, min_mean_diff, out_max, out_argmax, surfaces, surf_off);
+        else if (max_side <= 12)
+            hipLaunchKernelGGL(scan_pairs_mfma16_kernel<12>, dim3(mgrid), dim3(PS_WAVES * WAVE), 0, st, tbase, rbase, pd,
+                               npairs, max_side, min_std, min_mean_diff, out_max, out_argmax, surfaces, surf_off);
+        else
+            hipLaunchKernelGGL(scan_pairs_mfma16_kernel<16>, dim3(mgrid), dim3(PS_WAVES * WAVE), 0, st, tbase, rbase, pd,
+                               npairs, max_side, min_std, min_mean_diff, out_max, out_argmax, surfaces, surf_off);
+        SV_LAUNCH_CHECK();
+        return SVAMD_OK;
+    }
     if (acc_precision == SVAMD_ACC_F32 && max_side <= PM_SIDE && max_side > PM_MIN_SIDE && !mfma_off) {
         // one wavefront per pair on the matrix cores; three workgroups of four wavefronts fit a CU
         const int64_t groups = (npairs + PM_WAVES - 1) / PM_WAVES;
