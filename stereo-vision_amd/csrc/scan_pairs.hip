@@ -1058,7 +1058,6 @@ constexpr int PM_TROWS = PM_SIDE;
 constexpr int PM_RP = 2 * PM_SIDE;        // region row pitch
 constexpr int PM_SLOT_FLOATS = PM_TROWS * PM_TP + PM_SIDE * PM_RP + 8;   // + the reach of the reads requested ahead
 constexpr int PM_WAVES = 4;               // independent wavefronts (pairs) per workgroup
-constexpr int PM_MIN_SIDE = 0;            // smaller pairs keep the kernel in which several share a wavefront
 
 __global__ void __launch_bounds__(PM_WAVES * WAVE, 3)
 scan_pairs_mfma_kernel(const double *__restrict__ tbase, const double *__restrict__ rbase,
@@ -1554,6 +1553,187 @@ scan_pairs_mfma16_kernel(const double *__restrict__ tbase, const double *__restr
     }
 }
 
+// Sides 33 ... 64: one pair per workgroup of T wavefronts (T = 3 up to 48, else 4) on
+// v_mfma_f32_16x16x4_f32.  The surface is cut into 16 x 16 tiles; wavefront w owns the
+// tiles of columns 16 w ... 16 w + 15, so that one step reads T template operands (one per
+// row tile) and one region operand for T instructions.  Operand images as above (the
+// template not doubled: a select per row and tile; the region wrapped to nloop + 16 T
+// columns), sized by the call's largest side.  Float32 sums are folded into float64 after
+// at most 256 products.
+typedef float pm4 __attribute__((ext_vector_type(4)));
+
+__host__ __device__ inline int pw_round4(int v) { return (v + 3) & ~3; }
+__host__ __device__ inline int pw_tp(int max_side) { return pw_round4(max_side) + 1; }
+__host__ __device__ inline int pw_rp(int max_side, int tiles) { return pw_round4(max_side) + 16 * tiles + 4; }
+
+template <int T>
+__global__ void __launch_bounds__(T * WAVE)
+scan_pairs_mfma_wide_kernel(const double *__restrict__ tbase, const double *__restrict__ rbase,
+                            const PairDesc *__restrict__ desc, int64_t npairs, int max_side, double min_std,
+                            double min_mean_diff, double *__restrict__ out_max, int64_t *__restrict__ out_argmax,
+                            double *__restrict__ surfaces, const int64_t *__restrict__ surf_off)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    __shared__ double red[17];
+    __shared__ double red_d[4];
+    __shared__ int red_i[8];
+    const int tp = pw_tp(max_side), rp = pw_rp(max_side, T);
+    float *Tt = reinterpret_cast<float *>(smem_raw), *Rr = Tt + max_side * tp;
+    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+    constexpr int NTHR = T * WAVE;
+
+    for (int64_t p = blockIdx.x; p < npairs; p += gridDim.x) {
+        const PairDesc d = desc[p];
+        __syncthreads();            // the images are rewritten
+        if (!pair_desc_ok(d, max_side) || max_side > 16 * T) {
+            if (threadIdx.x == 0) {
+                out_max[p] = NAN;
+                if (out_argmax)
+                    out_argmax[p] = -1;
+            }
+            continue;
+        }
+        const int th = (int)d.t_h, tw = (int)d.t_w, rh = (int)d.r_h, rw = (int)d.r_w;
+        const int tn = th * tw, rn = rh * rw;
+        const int mh = min(th, rh), mw = min(tw, rw);
+        const int nloop = pw_round4(mw);
+        const double *Tl = tbase + d.t_off + lane, *Rl = rbase + d.r_off + lane;
+        const bool tcol = lane < tw, rcol = lane < rw;
+        // pass 1: means (wavefront w walks rows w, w + T, ...)
+        double ts = 0.0, rs = 0.0;
+        for (int y = wave; y < max(th, rh); y += T) {
+            if (tcol && y < th)
+                ts += Tl[y * d.t_pitch];
+            if (rcol && y < rh)
+                rs += Rl[y * d.r_pitch];
+        }
+        pair_sum2(ts, rs, red, NTHR);
+        const double tmean = ts / (double)tn, rmean = rs / (double)rn;
+        // pass 2: squared deviations, and the images on the way.  Column x of the wrapped
+        // region image holds column x mod rw: fetched from the lane that keeps it.
+        double tq = 0.0, rq = 0.0;
+        const int src0 = 4 * (lane % rw), src1 = 4 * ((lane + WAVE) % rw);
+        for (int y = wave; y < max(th, rh); y += T) {
+            double tv = 0.0, rv = 0.0;
+            if (tcol && y < th) {
+                tv = Tl[y * d.t_pitch] - tmean;
+                tq = fma(tv, tv, tq);
+            }
+            if (rcol && y < rh) {
+                rv = Rl[y * d.r_pitch] - rmean;
+                rq = fma(rv, rv, rq);
+            }
+            if (y < rh) {
+                // zeros beyond the template's own rows and columns
+                if (lane < tp)
+                    Tt[y * tp + lane] = (y < mh && lane < mw) ? (float)tv : 0.0f;
+                const int bits = __float_as_int((float)rv);
+                const float w0 = __int_as_float(__builtin_amdgcn_ds_bpermute(src0, bits));
+                const float w1 = __int_as_float(__builtin_amdgcn_ds_bpermute(src1, bits));
+                Rr[y * rp + lane] = w0;
+                if (lane + WAVE < rp)
+                    Rr[y * rp + lane + WAVE] = w1;
+            }
+        }
+        pair_sum2(tq, rq, red, NTHR);
+        const double tstd = sqrt(tq / (double)tn), rstd = sqrt(rq / (double)rn);
+        double *surf = surfaces ? surfaces + surf_off[p] : nullptr;
+        if (tstd < min_std) {      // homogeneous template: constant surface
+            const double fill = fabs(tmean - rmean) < min_mean_diff ? 1.0 : 0.0;
+            if (surf)
+                for (int i = threadIdx.x; i < rn; i += NTHR)
+                    surf[i] = fill;
+            if (threadIdx.x == 0) {
+                out_max[p] = fill;
+                if (out_argmax)
+                    out_argmax[p] = 0;
+            }
+            continue;
+        }
+        __syncthreads();
+        const double scale = tn == 0 ? ((rstd > 0.0) ? 0.0 : NAN) : 1.0 / (tstd * (double)tn) / rstd;
+
+        // ---- the surface: lane (kk, i) of an instruction supplies step n0 + kk of row /
+        // column i of the tile ----
+        const int li = lane & 15, kq = lane >> 4;
+        pm4 acc[T];
+        double dsum[T][4];
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                acc[t][v] = 0.0f;
+                dsum[t][v] = 0.0;
+            }
+        if (tn != 0) {
+            int kc[T];
+            const float *pa_lo[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                kc[t] = min(16 * t + li, rh - 1);       // rows beyond the surface repeat its last row
+                pa_lo[t] = Tt - kc[t] * tp + kq;
+            }
+            const float *pb = Rr + 16 * wave + li + kq;
+            const int flush_rows = max(256 / max(nloop, 1), 1);
+            int since = 0;
+            for (int m = 0; m < rh; ++m) {
+                const float *ra[T];
+#pragma unroll
+                for (int t = 0; t < T; ++t)
+                    ra[t] = pa_lo[t] + (m >= kc[t] ? m : m + rh) * tp;
+                const float *rb = pb + m * rp;
+                for (int n = 0; n < nloop; n += 4) {
+                    const float b = rb[n];
+                    float a[T];
+#pragma unroll
+                    for (int t = 0; t < T; ++t)
+                        a[t] = ra[t][n];
+#pragma unroll
+                    for (int t = 0; t < T; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b, acc[t], 0, 0, 0);
+                }
+                if (++since == flush_rows || m == rh - 1) {
+                    since = 0;
+#pragma unroll
+                    for (int t = 0; t < T; ++t)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            dsum[t][v] += (double)acc[t][v];
+                            acc[t][v] = 0.0f;
+                        }
+                }
+            }
+        }
+        // element v of tile t in a lane: row 16 t + 4 (lane / 16) + v, column 16 w + lane % 16
+        BestNan mine;
+        mine.best = -INFINITY;
+        mine.arg = 0x7fffffff;
+        mine.has_nan = 0;
+        const int l = 16 * wave + li;
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int k = 16 * t + 4 * kq + v;
+                const bool valid = k < rh && l < rw;
+                const double val = tn == 0 ? scale : dsum[t][v] * scale;
+                const int idx = k * rw + l;
+                if (surf && valid)
+                    surf[idx] = val;
+                mine.has_nan |= (valid && isnan(val)) ? 1 : 0;
+                const bool better = valid && val > mine.best;      // ascending index inside the lane
+                mine.best = better ? val : mine.best;
+                mine.arg = better ? idx : mine.arg;
+            }
+        const BestNan all = block_best(mine, red_d, red_i);
+        if (threadIdx.x == 0) {
+            out_max[p] = all.has_nan ? NAN : all.best;
+            if (out_argmax)
+                out_argmax[p] = all.arg == 0x7fffffff ? -1 : all.arg;
+        }
+    }
+}
+
 // image_scan's sequential selection rule, one thread per window.
 __global__ void __launch_bounds__(256)
 scan_fold_kernel(const double *__restrict__ corr_max, const uint8_t *__restrict__ is_centre,
@@ -1628,7 +1808,7 @@ int launch_pairs(const double *tbase, const double *rbase, const int64_t *desc, 
     const int tasks = max_side * ((max_side + w64 - 1) / w64);
     const int threads = tasks <= 64 ? 64 : tasks <= 128 ? 128 : 256;
     const unsigned grid = list ? list_grid : (unsigned)(npairs < (1 << 20) ? npairs : (1 << 20));
-    // SVAMD_PAIR_MFMA=0 keeps the vector-ALU kernel for sides up to 32 (measurements only)
+    // SVAMD_PAIR_MFMA=0 keeps the vector-ALU kernel for every side (measurements only)
     static const bool mfma_off = getenv("SVAMD_PAIR_MFMA") && atoi(getenv("SVAMD_PAIR_MFMA")) == 0;
     if (acc_precision == SVAMD_ACC_F32 && max_side <= PS_SIDE && !mfma_off) {
         // four pairs per wavefront on the matrix cores
@@ -1646,12 +1826,31 @@ int launch_pairs(const double *tbase, const double *rbase, const int64_t *desc, 
         SV_LAUNCH_CHECK();
         return SVAMD_OK;
     }
-    if (acc_precision == SVAMD_ACC_F32 && max_side <= PM_SIDE && max_side > PM_MIN_SIDE && !mfma_off) {
+    if (acc_precision == SVAMD_ACC_F32 && max_side <= PM_SIDE && !mfma_off) {
         // one wavefront per pair on the matrix cores; three workgroups of four wavefronts fit a CU
         const int64_t groups = (npairs + PM_WAVES - 1) / PM_WAVES;
         const unsigned mgrid = (unsigned)(groups < 256 * 3 ? groups : 256 * 3);
         hipLaunchKernelGGL(scan_pairs_mfma_kernel, dim3(mgrid), dim3(PM_WAVES * WAVE), 0, st, tbase, rbase, pd, npairs,
                            max_side, min_std, min_mean_diff, out_max, out_argmax, surfaces, surf_off);
+        SV_LAUNCH_CHECK();
+        return SVAMD_OK;
+    }
+    // Sides above 32 are covered by 48 x 48 or 64 x 64 tiles: the matrix cores win where the
+    // side fills them (45 ... 48: 79 against 61 TFLOP/s; 56: 80 against 73; 60: 93 against 67;
+    // 64: 107 against 78), the vector kernel where a third or more of the tiles would be
+    // padding (40: 57 against 65; 50: 60 against 65).
+    const bool wide_fits = (max_side >= 45 && max_side <= 48) || max_side >= 55;
+    if (acc_precision == SVAMD_ACC_F32 && max_side > PM_SIDE && wide_fits && !mfma_off) {
+        // one pair per workgroup, a wavefront per strip of 16 surface columns
+        const int tiles = max_side <= 48 ? 3 : 4;
+        const size_t lds = ((size_t)max_side * pw_tp(max_side) + (size_t)max_side * pw_rp(max_side, tiles)) * sizeof(float);
+        const unsigned wgrid = (unsigned)(npairs < 256 * 8 ? npairs : 256 * 8);
+        if (tiles == 3)
+            hipLaunchKernelGGL(scan_pairs_mfma_wide_kernel<3>, dim3(wgrid), dim3(3 * WAVE), lds, st, tbase, rbase, pd,
+                               npairs, max_side, min_std, min_mean_diff, out_max, out_argmax, surfaces, surf_off);
+        else
+            hipLaunchKernelGGL(scan_pairs_mfma_wide_kernel<4>, dim3(wgrid), dim3(4 * WAVE), lds, st, tbase, rbase, pd,
+                               npairs, max_side, min_std, min_mean_diff, out_max, out_argmax, surfaces, surf_off);
         SV_LAUNCH_CHECK();
         return SVAMD_OK;
     }
