@@ -7,10 +7,14 @@
 // region staged in LDS, and the surface evaluated directly,
 //     c[k][l] = sum_{m<mh, n<mw} t'[m][n] * r'[(m + k) mod rh][(n + l) mod rw],
 // which is what conj(FFT(t')) * FFT(r') transforms back to.  Statistics, scaling
-// and the max-reduction are float64.  The multiply-accumulate runs either in
-// float64 (scan_pairs_kernel: one workgroup per pair, four surface elements per
-// thread) or in float32 with packed FMAs (scan_pairs_f32_kernel: one wavefront
-// per group of pairs, short float32 runs folded into float64).
+// and the max-reduction are float64.  The multiply-accumulate runs in float64
+// (scan_pairs_kernel: one workgroup per pair) or in float32 with short runs folded
+// into float64: on the matrix cores, the sum read as a matrix product
+// (scan_pairs_mfma16_kernel: four pairs of sides up to 16 per wavefront;
+// scan_pairs_mfma_kernel: one pair of sides up to 32 per wavefront;
+// scan_pairs_mfma_wide_kernel: one pair of sides up to 64 per workgroup), or with packed
+// FMAs on the vector ALU (scan_pairs_f32_kernel) for the sides whose surfaces would
+// leave most of a matrix tile empty.  launch_pairs() holds the choice per side.
 #include <algorithm>
 #include <cstdlib>
 
@@ -1826,7 +1830,9 @@ int launch_pairs(const double *tbase, const double *rbase, const int64_t *desc, 
         SV_LAUNCH_CHECK();
         return SVAMD_OK;
     }
-    if (acc_precision == SVAMD_ACC_F32 && max_side <= PM_SIDE && !mfma_off) {
+    // Sides 17 ... 20 fill two fifths of a 32 x 32 tile or less: the vector kernel is 10 - 15 % faster there
+    // (20: 37.5 against 34 TFLOP/s), from 21 on the matrix cores win (21: 36 against 26).
+    if (acc_precision == SVAMD_ACC_F32 && max_side > 20 && max_side <= PM_SIDE && !mfma_off) {
         // one wavefront per pair on the matrix cores; three workgroups of four wavefronts fit a CU
         const int64_t groups = (npairs + PM_WAVES - 1) / PM_WAVES;
         const unsigned mgrid = (unsigned)(groups < 256 * 3 ? groups : 256 * 3);
