@@ -701,18 +701,20 @@ def test_scan_pairs_vs_oracle(mods, oracle):
         assert_surface_close(out.cpu().numpy(), want, tol, f'pairs precision {precision}')
 
 
-@pytest.mark.parametrize('max_side', [8, 12, 16, 20, 27])
+@pytest.mark.parametrize('max_side', [8, 12, 16, 20, 27, 31, 32, 40, 46, 56, 60, 64])
 def test_scan_pairs_shared_wavefronts_mixed_sizes(mods, oracle, max_side):
-    '''Small pairs share a wavefront (several LDS slots side by side, loop bounds taken
-    from the largest pair of the wavefront): boxes of every size up to max_side in
-    one call, float32 and float64 accumulation against the oracle.'''
+    '''Boxes of every size up to max_side in one call, float32 and float64 accumulation
+    against the oracle.  The sides pick the float32 kernel: four pairs per wavefront on the
+    matrix cores (up to 16; step counts taken from the largest pair of the wavefront), the
+    vector kernel (20, 40), one pair per wavefront (27, 31, 32) or per workgroup (46: three
+    strips of 16 columns, 56 - 64: four) on the matrix cores.'''
     import torch
     nv = mods['n']
     rng = np.random.default_rng(max_side)
-    H, W = 48, 80
+    H, W = (48, 80) if max_side <= 32 else (80, 112)
     left, right = rng.random((H, W)), rng.random((H, W))
     boxes = []
-    for _ in range(400):
+    for _ in range(400 if max_side <= 32 else 120):
         th, tw, rh, rw = rng.integers(1, max_side + 1, size=4)
         ty, tx = rng.integers(0, H - th + 1), rng.integers(0, W - tw + 1)
         ry, rx = rng.integers(0, H - rh + 1), rng.integers(0, W - rw + 1)
@@ -730,14 +732,14 @@ def test_scan_pairs_shared_wavefronts_mixed_sizes(mods, oracle, max_side):
 
 
 def test_scan_pairs_random_boxes_f32_against_f64(mods):
-    '''Random batches of boxes (sides 1..48: every staging mode of the float32 kernel;
+    '''Random batches of boxes (sides 1..64: every float32 kernel and staging mode;
     templates larger than regions, empty templates, NaN pixels, constant patches): the float32 kernel's surfaces against the
     float64 kernel's, same NaN pattern, values within 2e-5.'''
     import torch
     nv = mods['n']
     rng = np.random.default_rng(11)
     H, W = 96, 128
-    for trial in range(36):
+    for trial in range(48):
         left, right = rng.random((H, W)), rng.random((H, W))
         if trial % 3 == 0:
             left[rng.random((H, W)) < 0.01] = np.nan
@@ -745,8 +747,8 @@ def test_scan_pairs_random_boxes_f32_against_f64(mods):
         if trial % 5 == 0:
             right[10:40, 20:70] = 0.25
             left[50:70, 30:60] = 0.5
-        # sides up to 16: rows of 16 lanes; 21..32: columns in registers on two wavefronts; else sweeps
-        max_side = int(rng.integers(2, 17)) if trial % 2 == 0 else int(rng.integers(17, 49))
+        # the largest side picks the kernel (launch_pairs): matrix cores up to 16, 21..32, 45..48, 55..64
+        max_side = int(rng.integers(2, 17)) if trial % 2 == 0 else int(rng.integers(17, 65))
         n = int(rng.integers(1, 400 if max_side <= 16 else 60))
         th = rng.integers(0 if trial % 7 == 0 else 1, max_side + 1, size=n)
         tw, rh, rw = (rng.integers(1, max_side + 1, size=n) for _ in range(3))
