@@ -1058,20 +1058,24 @@ scan_pairs_f32_kernel(const double *__restrict__ tbase, const double *__restrict
 typedef float pm16 __attribute__((ext_vector_type(16)));
 constexpr int PM_SIDE = 32;
 constexpr int PM_TP = 33;                 // template row pitch: the 32 rows of an A read on 32 banks
-constexpr int PM_TROWS = PM_SIDE;
-constexpr int PM_RP = 2 * PM_SIDE;        // region row pitch
-constexpr int PM_SLOT_FLOATS = PM_TROWS * PM_TP + PM_SIDE * PM_RP + 8;   // + the reach of the reads requested ahead
 constexpr int PM_WAVES = 4;               // independent wavefronts (pairs) per workgroup
 
-__global__ void __launch_bounds__(PM_WAVES * WAVE, 3)
+// ROWS: the largest side of the call, rounded up to 26 or 32 (rows a lane keeps, rows and
+// columns of the LDS images); SETS: accumulator tiles, one per ROWS / SETS rows (at most 256
+// products each).  Up to 26 the images are small enough for four wavefronts per SIMD.
+template <int ROWS, int SETS>
+__global__ void __launch_bounds__(PM_WAVES * WAVE, ROWS <= 26 ? 4 : 3)
 scan_pairs_mfma_kernel(const double *__restrict__ tbase, const double *__restrict__ rbase,
                        const PairDesc *__restrict__ desc, int64_t npairs, int max_side, double min_std,
                        double min_mean_diff, double *__restrict__ out_max, int64_t *__restrict__ out_argmax,
                        double *__restrict__ surfaces, const int64_t *__restrict__ surf_off)
 {
+    constexpr int HALF = ROWS / 2;                                   // rows per lane
+    constexpr int PM_RP = ((ROWS + 3) & ~3) + PM_SIDE;               // region row pitch
+    constexpr int PM_SLOT_FLOATS = ROWS * PM_TP + ROWS * PM_RP + 16; // + the reach of the reads requested ahead
     __shared__ float slots[PM_WAVES * PM_SLOT_FLOATS];
     const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
-    float *Tt = slots + wave * PM_SLOT_FLOATS, *Rr = Tt + PM_TROWS * PM_TP;
+    float *Tt = slots + wave * PM_SLOT_FLOATS, *Rr = Tt + ROWS * PM_TP;
     const int lx = lane & 31, ly = lane >> 5;
     const int64_t first = (int64_t)blockIdx.x * PM_WAVES + wave, stride = (int64_t)gridDim.x * PM_WAVES;
 
@@ -1080,29 +1084,29 @@ scan_pairs_mfma_kernel(const double *__restrict__ tbase, const double *__restric
     // where it is used.  (Nothing is requested a pair ahead: the 64 registers that would
     // hold cost the third wavefront per SIMD, and with three wavefronts two compute while
     // one waits.)
-    double tk[PM_SIDE / 2], rk[PM_SIDE / 2];
+    double tk[HALF], rk[HALF];
     auto request = [&](const PairDesc &d, bool ok) {
         const int th = (int)d.t_h, tw = (int)d.t_w, rh = (int)d.r_h, rw = (int)d.r_w;
         if (ok && th > 0 && tw > 0) {
             const double *T = tbase + d.t_off;
             const unsigned pitch = (unsigned)d.t_pitch, cx = (unsigned)min(lx, tw - 1);
 #pragma unroll
-            for (int j = 0; j < PM_SIDE / 2; ++j)
+            for (int j = 0; j < HALF; ++j)
                 tk[j] = T[(unsigned)min(ly + 2 * j, th - 1) * pitch + cx];
         } else {
 #pragma unroll
-            for (int j = 0; j < PM_SIDE / 2; ++j)
+            for (int j = 0; j < HALF; ++j)
                 tk[j] = 0.0;
         }
         if (ok) {
             const double *R = rbase + d.r_off;
             const unsigned pitch = (unsigned)d.r_pitch, cx = (unsigned)min(lx, rw - 1);
 #pragma unroll
-            for (int j = 0; j < PM_SIDE / 2; ++j)
+            for (int j = 0; j < HALF; ++j)
                 rk[j] = R[(unsigned)min(ly + 2 * j, rh - 1) * pitch + cx];
         } else {
 #pragma unroll
-            for (int j = 0; j < PM_SIDE / 2; ++j)
+            for (int j = 0; j < HALF; ++j)
                 rk[j] = 0.0;
         }
     };
@@ -1133,14 +1137,14 @@ scan_pairs_mfma_kernel(const double *__restrict__ tbase, const double *__restric
         return d;
     };
     PairDesc d_next = unpack(desc_word(first));
-    bool ok_next = first < npairs && pair_desc_ok(d_next, max_side) && max_side <= PM_SIDE;
+    bool ok_next = first < npairs && pair_desc_ok(d_next, max_side) && max_side <= ROWS;
     int64_t w_after = desc_word(first + stride);
     for (int64_t p = first; p < npairs; p += stride) {
         const PairDesc d = d_next;
         const bool ok = ok_next;
         request(d, ok);
         d_next = unpack(w_after);
-        ok_next = p + stride < npairs && pair_desc_ok(d_next, max_side) && max_side <= PM_SIDE;
+        ok_next = p + stride < npairs && pair_desc_ok(d_next, max_side) && max_side <= ROWS;
         w_after = desc_word(p + 2 * stride);
         if (!ok) {
             if (lane == 0) {
@@ -1157,7 +1161,7 @@ scan_pairs_mfma_kernel(const double *__restrict__ tbase, const double *__restric
         PAIR_STAMP(6);          // descriptor of the next pair
         double ts = 0.0, rs = 0.0;
 #pragma unroll
-        for (int j = 0; j < PM_SIDE / 2; ++j) {
+        for (int j = 0; j < HALF; ++j) {
             const int y = ly + 2 * j;
             tk[j] = (lx < tw && y < th) ? tk[j] : 0.0;
             rk[j] = (lx < rw && y < rh) ? rk[j] : 0.0;
@@ -1168,7 +1172,7 @@ scan_pairs_mfma_kernel(const double *__restrict__ tbase, const double *__restric
         const double tmean = wave_sum(ts) / (double)tn, rmean = wave_sum(rs) / (double)rn;
         double tq = 0.0, rq = 0.0;
 #pragma unroll
-        for (int j = 0; j < PM_SIDE / 2; ++j) {
+        for (int j = 0; j < HALF; ++j) {
             const int y = ly + 2 * j;
             tk[j] = (lx < tw && y < th) ? tk[j] - tmean : 0.0;
             rk[j] = (lx < rw && y < rh) ? rk[j] - rmean : 0.0;
@@ -1202,23 +1206,25 @@ scan_pairs_mfma_kernel(const double *__restrict__ tbase, const double *__restric
             const int src0 = 4 * ((lx % rw) + 32 * ly), src1 = 4 * (((lx + 32) % rw) + 32 * ly);
             float *tcol = Tt + lx, *rcol = Rr + lx;
 #pragma unroll
-            for (int j = 0; j < PM_SIDE / 2; ++j) {
+            for (int j = 0; j < HALF; ++j) {
                 const int y = ly + 2 * j;
                 // zeros beyond the template's own rows and columns (the 32 lanes of a row cover
                 // every column a step reads, the 32 rows every row)
                 tcol[y * PM_TP] = (y < mh && lx < mw) ? (float)tk[j] : 0.0f;
                 const int rv = __float_as_int((float)rk[j]);
                 rcol[y * PM_RP] = __int_as_float(__builtin_amdgcn_ds_bpermute(src0, rv));
-                rcol[y * PM_RP + PM_SIDE] = __int_as_float(__builtin_amdgcn_ds_bpermute(src1, rv));
+                const float w1 = __int_as_float(__builtin_amdgcn_ds_bpermute(src1, rv));
+                if (PM_RP >= 2 * PM_SIDE || lx + PM_SIDE < PM_RP)      // columns from PM_RP on are the next row's
+                    rcol[y * PM_RP + PM_SIDE] = w1;
             }
         }
         __builtin_amdgcn_wave_barrier();
         PAIR_STAMP(2);          // staging
 
         // ---- the surface ----
-        pm16 acc[4];
+        pm16 acc[SETS];
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < SETS; ++q)
 #pragma unroll
             for (int v = 0; v < 16; ++v)
                 acc[q][v] = 0.0f;
@@ -1227,25 +1233,42 @@ scan_pairs_mfma_kernel(const double *__restrict__ tbase, const double *__restric
             const int kk = min(lx, rh - 1);
             const float *pa_lo = Tt - kk * PM_TP + ly, *pa_hi = pa_lo + rh * PM_TP;   // + m' * PM_TP + n
             const float *pb = Rr + lx + ly;                                          // + m' * PM_RP + n
-            const int rows_q = (rh + 3) / 4;
+            const int rows_q = (rh + SETS - 1) / SETS;
             const int chunks = nloop / 4;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < SETS; ++q) {
                 const int m_end = min((q + 1) * rows_q, rh);
                 for (int m = q * rows_q; m < m_end; ++m) {
                     const float *ra = (m >= kk ? pa_lo : pa_hi) + m * PM_TP, *rb = pb + m * PM_RP;
+                    // two chunks per round, each chunk's operands requested a chunk ahead (past the
+                    // row's end they are read and dropped: still inside the slot); the scheduling
+                    // barriers keep the requests ahead of the products they hide behind
+                    // (measured: +3 % with three accumulator sets and four wavefronts per SIMD, -3 %
+                    // with four sets and three wavefronts, which therefore keep the plain loop)
                     float a0 = ra[0], a1 = ra[2], b0 = rb[0], b1 = rb[2];
-                    for (int c = 0; c < chunks; ++c) {
-                        // the next chunk's operands are requested before this chunk's products
-                        // (past the row's end they are read and dropped: still inside the slot)
+                    int c = 0;
+                    for (; SETS < 4 && c + 2 <= chunks; c += 2) {
+                        const float na0 = ra[4 * c + 4], na1 = ra[4 * c + 6];
+                        const float nb0 = rb[4 * c + 4], nb1 = rb[4 * c + 6];
+                        __builtin_amdgcn_sched_barrier(0);
+                        acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[q], 0, 0, 0);
+                        acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[q], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        a0 = ra[4 * c + 8];
+                        a1 = ra[4 * c + 10];
+                        b0 = rb[4 * c + 8];
+                        b1 = rb[4 * c + 10];
+                        __builtin_amdgcn_sched_barrier(0);
+                        acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(na0, nb0, acc[q], 0, 0, 0);
+                        acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(na1, nb1, acc[q], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    for (; c < chunks; ++c) {
                         const float na0 = ra[4 * c + 4], na1 = ra[4 * c + 6];
                         const float nb0 = rb[4 * c + 4], nb1 = rb[4 * c + 6];
                         acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[q], 0, 0, 0);
                         acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[q], 0, 0, 0);
-                        a0 = na0;
-                        a1 = na1;
-                        b0 = nb0;
-                        b1 = nb1;
+                        a0 = na0, a1 = na1, b0 = nb0, b1 = nb1;
                     }
                 }
             }
@@ -1262,7 +1285,11 @@ scan_pairs_mfma_kernel(const double *__restrict__ tbase, const double *__restric
         for (int v = 0; v < 16; ++v) {
             const int k0 = 8 * (v / 4) + (v % 4);            // + 4 ly
             const bool valid = k0 + 4 * ly < rh && lx < rw;
-            const double sum = ((double)acc[0][v] + (double)acc[1][v]) + ((double)acc[2][v] + (double)acc[3][v]);
+            double sum = (double)acc[0][v];
+#pragma unroll
+            for (int q = 1; q < SETS; ++q) {
+                sum += (double)acc[q][v];
+            }
             const double val = tn == 0 ? scale : sum * scale;
             const int idx = idx0 + k0 * rw;
             mine.has_nan |= (valid && isnan(val)) ? 1 : 0;
@@ -1274,7 +1301,11 @@ scan_pairs_mfma_kernel(const double *__restrict__ tbase, const double *__restric
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
                 const int k0 = 8 * (v / 4) + (v % 4);
-                const double sum = ((double)acc[0][v] + (double)acc[1][v]) + ((double)acc[2][v] + (double)acc[3][v]);
+                double sum = (double)acc[0][v];
+#pragma unroll
+                for (int q = 1; q < SETS; ++q) {
+                    sum += (double)acc[q][v];
+                }
                 if (k0 + 4 * ly < rh && lx < rw)
                     surf[idx0 + k0 * rw] = tn == 0 ? scale : sum * scale;
             }
@@ -1833,11 +1864,16 @@ int launch_pairs(const double *tbase, const double *rbase, const int64_t *desc, 
     // Sides 17 ... 20 fill two fifths of a 32 x 32 tile or less: the vector kernel is 10 - 15 % faster there
     // (20: 37.5 against 34 TFLOP/s), from 21 on the matrix cores win (21: 36 against 26).
     if (acc_precision == SVAMD_ACC_F32 && max_side > 20 && max_side <= PM_SIDE && !mfma_off) {
-        // one wavefront per pair on the matrix cores; three workgroups of four wavefronts fit a CU
+        // one wavefront per pair on the matrix cores; three workgroups of four wavefronts fit a CU (four up to 26 x 26)
         const int64_t groups = (npairs + PM_WAVES - 1) / PM_WAVES;
-        const unsigned mgrid = (unsigned)(groups < 256 * 3 ? groups : 256 * 3);
-        hipLaunchKernelGGL(scan_pairs_mfma_kernel, dim3(mgrid), dim3(PM_WAVES * WAVE), 0, st, tbase, rbase, pd, npairs,
-                           max_side, min_std, min_mean_diff, out_max, out_argmax, surfaces, surf_off);
+        const int64_t resident = 256 * (max_side <= 26 ? 4 : 3);
+        const unsigned mgrid = (unsigned)(groups < resident ? groups : resident);
+        if (max_side <= 26)
+            hipLaunchKernelGGL((scan_pairs_mfma_kernel<26, 3>), dim3(mgrid), dim3(PM_WAVES * WAVE), 0, st, tbase, rbase, pd,
+                               npairs, max_side, min_std, min_mean_diff, out_max, out_argmax, surfaces, surf_off);
+        else
+            hipLaunchKernelGGL((scan_pairs_mfma_kernel<32, 4>), dim3(mgrid), dim3(PM_WAVES * WAVE), 0, st, tbase, rbase, pd,
+                               npairs, max_side, min_std, min_mean_diff, out_max, out_argmax, surfaces, surf_off);
         SV_LAUNCH_CHECK();
         return SVAMD_OK;
     }
