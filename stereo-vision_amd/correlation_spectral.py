@@ -62,7 +62,7 @@ def _small_pair_surface(template, region):
 
 def cross_correlate_2d_spectral_batched(templates, regions, out_dtype=np.float32):
     '''`cross_correlate_2d_spectral` for a stack of pairs at once: templates
-    [B, th, tw] and regions [B, H, W] with H and W powers of two (4..1024),
+    [B, th, tw] and regions [B, H, W] with H and W powers of two (4..4096),
     through the batched LDS FFT kernels.  Returns [B, H, W] of out_dtype.  Inputs
     are used as float32.'''
     torch = nv.torch_cuda()

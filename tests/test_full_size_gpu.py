@@ -140,6 +140,48 @@ def mods_spectral():
     return correlation_spectral
 
 
+@pytest.mark.parametrize('batch,tshape,rshape', [
+    (1, (256, 256), (256, 256)), (3, (512, 512), (512, 512)), (1, (4096, 4096), (4096, 4096)),
+    (2, (256, 512), (256, 512)), (1, (2048, 256), (2048, 256)), (1, (4096, 1024), (4096, 1024)),
+    (2, (256, 4096), (256, 4096)), (2, (300, 200), (512, 256)), (1, (700, 3000), (512, 2048)),
+    (1, (4096, 4000), (4096, 4096))])
+def test_fft_every_wide_size_and_mixed_shapes(mods_spectral, oracle, batch, tshape, rshape):
+    """Every transform length of the N / 16-threads-per-transform kernels (256 ... 4096) as
+    rows and as columns, square and not, batches, zero-padded and cropped templates:
+    first and last pair of the batch against the float64 FFT evaluation of
+    correlation_spectral.py:37-54, float32 surfaces to 1e-5."""
+    rng = np.random.default_rng(tshape[0] * 7 + rshape[1])
+    t = rng.random((batch,) + tshape, dtype=np.float32)
+    r = rng.random((batch,) + rshape, dtype=np.float32) * 255
+    out = mods_spectral.cross_correlate_2d_spectral_batched(t, r)
+    assert out.shape == (batch,) + rshape and out.dtype == np.float32
+    for b in sorted({0, batch - 1}):
+        want = oracle.cross_correlate_2d_spectral_fft(t[b].astype(np.float64), r[b].astype(np.float64))
+        assert_surface_close(out[b], want, 1e-5, f'wide fft {tshape} over {rshape}, pair {b}')
+
+
+@pytest.mark.parametrize('n', [256, 512, 2048])
+def test_fft_wide_branches_and_planted_shift(mods_spectral, n):
+    """The reference's branches at the wide sizes (correlation_spectral.py:39-49): flat
+    template with a different / the same mean, constant region, and a rolled copy."""
+    rng = np.random.default_rng(n)
+    t = rng.random((5, n, n), dtype=np.float32)
+    r = rng.random((5, n, n), dtype=np.float32)
+    t[1] = 0.5
+    t[2] = 0.25
+    r[2] = 0.25
+    r[3] = 0.75
+    shift = (n - 3, n // 2 + 1)
+    r[4] = np.roll(t[4], shift, axis=(0, 1))
+    out = mods_spectral.cross_correlate_2d_spectral_batched(t, r)
+    assert np.all(out[1] == 0.0)
+    assert np.all(out[2] == 1.0)
+    assert np.isnan(out[3]).all()
+    assert tuple(int(v) for v in np.unravel_index(np.argmax(out[4]), out[4].shape)) == shift
+    assert abs(float(out[4].max()) - 1.0) < 1e-5
+    assert np.isfinite(out[0]).all() and np.abs(out[0]).max() < 0.1
+
+
 def test_million_pairs_sampled_against_the_oracle(oracle):
     '''2^20 circular 31 x 31 pairs in one call (the reference-faithful dense-scan
     arithmetic): a pair of identical boxes peaks at 1 at index 0, a random sample
