@@ -772,10 +772,11 @@ def test_scan_pairs_random_boxes_f32_against_f64(mods):
             assert np.nanmax(np.abs(m32 - m64)) < 2e-5
 
 
-@pytest.mark.parametrize('max_side', [12, 16])
+@pytest.mark.parametrize('max_side', [12, 16, 24, 32, 48, 64])
 def test_scan_pairs_narrow_pair_after_nan_pairs(mods, max_side):
     '''A pair clipped to a few columns shares its wavefront with full-size pairs and
-    walks their (wider) column range: what it reads beyond its own staging must be
+    walks their (wider) column range (sides up to 16), or walks whole tiles of the matrix
+    cores (above): what it reads beyond its own staging must be
     zeros, not what an earlier pair left in the LDS.  A first call fills every slot
     with NaN pixels; the second call's results must be finite and equal to the
     float64 kernel's (which gives every pair a workgroup of its own).'''
