@@ -200,6 +200,10 @@ extern "C" int svamd_scan_grid(const double *left, int64_t left_pitch, const dou
     const int64_t threads = nwin * slots;
     SV_REQUIRE((threads + 255) / 256 < ((int64_t)1 << 31), SVAMD_ERR_LIMIT,
                "scan_grid: too many candidates in one call; scan fewer window rows at a time");
+    // tables whose counts do not add up to `npairs` leave descriptors unwritten: those
+    // must read as empty boxes (a NaN pair), not as whatever the workspace held
+    if (npairs > 0)
+        SV_HIP(hipMemsetAsync(s.desc, 0, (size_t)npairs * 8 * sizeof(int64_t), st));
     hipLaunchKernelGGL(grid_enumerate_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, g, row_begin,
                        nwin, npairs, left_pitch, right_pitch, s.desc, s.is_centre, s.pair_slot, s.win_off);
     SV_LAUNCH_CHECK();

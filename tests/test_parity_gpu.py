@@ -772,6 +772,42 @@ def test_scan_pairs_random_boxes_f32_against_f64(mods):
             assert np.nanmax(np.abs(m32 - m64)) < 2e-5
 
 
+@pytest.mark.parametrize('max_side', [8, 16, 20, 24, 32, 40, 48, 64])
+def test_scan_pairs_empty_boxes_in_every_kernel(mods, max_side):
+    """All-zero descriptors (what svamd_scan_grid leaves for pairs its tables never name)
+    and empty regions between ordinary pairs: NaN and index -1 for them in every float32
+    kernel and in the float64 kernel, the neighbours' results untouched."""
+    import torch
+    nv = mods['n']
+    rng = np.random.default_rng(100 + max_side)
+    H, W = 80, 96
+    left, right = rng.random((H, W)), rng.random((H, W))
+    m = max_side
+    boxes = []
+    for i in range(600):
+        y, x = int(rng.integers(0, H - m + 1)), int(rng.integers(0, W - m + 1))
+        if i % 5 == 1:
+            boxes.append((0,) * 8)
+        elif i % 5 == 3:
+            boxes.append((y * W + x, W, m, m, y * W + x, W, 0, m) if i % 2 else (y * W + x, W, m, m, y * W + x, W, m, 0))
+        else:
+            boxes.append((y * W + x, W, m, m, y * W + x, W, m, m))
+    desc = np.array(boxes, dtype=np.int64)
+    empty = (desc[:, 6] == 0) | (desc[:, 7] == 0)
+    dl, dr, dd = nv.to_device(left), nv.to_device(right), nv.to_device(desc)
+    outs = {}
+    for precision in (nv.ACC_F32, nv.ACC_F64):
+        out, arg = nv.empty(len(desc), torch.float64), nv.empty(len(desc), torch.int64)
+        nv.call('svamd_scan_pairs', nv.ptr(dl), nv.ptr(dr), nv.ptr(dd), len(desc), max_side, 1e-4, 1e-9,
+                precision, nv.ptr(out), nv.ptr(arg), None, None, nv.stream_ptr())
+        outs[precision] = (out.cpu().numpy(), arg.cpu().numpy())
+    for precision, (val, arg) in outs.items():
+        assert np.isnan(val[empty]).all() and np.all(arg[empty] == -1), precision
+        assert np.isfinite(val[~empty]).all(), precision
+    assert np.array_equal(outs[nv.ACC_F32][1], outs[nv.ACC_F64][1])
+    assert_surface_close(outs[nv.ACC_F32][0], outs[nv.ACC_F64][0], SURFACE_TOL, 'pairs next to empty boxes')
+
+
 @pytest.mark.parametrize('max_side', [12, 16, 24, 32, 48, 64])
 def test_scan_pairs_narrow_pair_after_nan_pairs(mods, max_side):
     '''A pair clipped to a few columns shares its wavefront with full-size pairs and
