@@ -239,7 +239,7 @@ int svamd_scan_grid(const double *left, int64_t left_pitch, const double *right,
  * these images into this workspace (e.g. one prepare, then one scan per row
  * shard).  Limits: win_w * win_h <= 1024 (exact float32 accumulation);
  * stride_x == 1; win_h rows of a 256-window-wide tile must fit in LDS (about 70
- * rows for narrow windows).  Window widths 7, 11, 15, 21, 25 and 31 have fully unrolled kernels;
+ * rows for narrow windows).  Window widths 3 ... 32 each have a fully unrolled kernel;
  * any other width runs through a kernel that takes it at run time. */
 size_t svamd_band_scan_u8_workspace_bytes(int H, int W, int win_w, int win_h);
 
@@ -266,7 +266,7 @@ int svamd_band_scan_u8(const uint8_t *left, const uint8_t *right, int H, int W,
  * the centred pixels; windows too flat for the tables' rounding take them from their own
  * pixels, and exactly constant windows give NaN scores (the reference's 0 / 0).
  * Images with NaN pixels are not supported.  Limits: win_w * win_h <= 4096,
- * stride_x == 1, the LDS tile as above.  Widths 25 and 31 have unrolled kernels. */
+ * stride_x == 1, the LDS tile as above.  Widths 5, 7, 9-12, 15, 16, 20, 21, 24, 25 and 31 have unrolled kernels. */
 size_t svamd_band_scan_f64_workspace_bytes(int H, int W, int win_w, int win_h);
 /* byte offset, inside that workspace, of an int32 that holds after a scan the number of
  * windows that were evaluated again in float64 (a diagnostic) */

@@ -21,7 +21,7 @@ import bench  # noqa: E402
 
 H = W = 4096
 WIN, MD = 31, int(os.environ.get('AB_MAX_DISP', 128))
-WIN_W = int(os.environ.get('AB_WIN_W', WIN))      # a width other than 7/11/15/21/31 takes the run-time-width kernel
+WIN_W = int(os.environ.get('AB_WIN_W', WIN))      # widths above 32 take the run-time-width kernel
 
 
 def load(path):

@@ -24,7 +24,7 @@ import sv_image_comparison as _svic
 # float64 ones; evaluations that cannot promise that are sent to float64 regardless.
 BAND_GUARD_BAND = 1e-5
 
-WINDOW_WIDTHS = (7, 11, 15, 21, 25, 31)   # widths with a fully unrolled kernel; others take the run-time-width one
+WINDOW_WIDTHS = tuple(range(3, 33))   # widths with a fully unrolled kernel; others take the run-time-width one
 
 
 def as_uint8_image(image):

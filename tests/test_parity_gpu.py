@@ -868,7 +868,8 @@ def synthetic_pair(h, w, seed, max_shift):
 
 
 @pytest.mark.parametrize('win,h,w,md', [(31, 70, 300, 24), (31, 47, 140, 128), (15, 40, 90, 10),
-                                        (7, 33, 64, 5), (11, 30, 530, 3), (21, 50, 77, 9)])
+                                        (7, 33, 64, 5), (11, 30, 530, 3), (21, 50, 77, 9), (5, 20, 70, 4),
+                                        (10, 31, 150, 12), (12, 40, 90, 7), (20, 45, 200, 30), (24, 50, 310, 16)])
 def test_band_scan_vs_oracle(mods, oracle, win, h, w, md):
     left, right = synthetic_pair(h, w, win * 1000 + md, min(md, 12))
     left[5:5 + win, 3:3 + win] = 200                     # a constant window
@@ -884,6 +885,25 @@ def test_band_scan_vs_oracle(mods, oracle, win, h, w, md):
         odisp, oval = oracle.band_scan(left, right, win, win, md, mode='fold', threshold=thr)
         assert np.array_equal(disp, odisp)
         assert_surface_close(val, oval, 1e-12, 'band fold values')
+
+
+@pytest.mark.parametrize('win_w', list(range(3, 33)))
+def test_band_scan_every_unrolled_width(mods, oracle, win_w):
+    """Each window width from 3 to 32 has its own fully unrolled kernel for 8-bit images:
+    score volume, disparities and the selection rule against the oracle, with a window
+    height that is not the width."""
+    win_h = 9 + win_w % 5
+    left, right = synthetic_pair(36, 170, 500 + win_w, 7)
+    b = mods['b']
+    disp, val, scores = b.band_scan(left, right, win_w, win_h, 11, want_scores=True)
+    odisp, oval, oscores = oracle.band_scan(left, right, win_w, win_h, 11, want_scores=True)
+    assert_surface_close(scores, oscores, 1e-12, f'band scores, width {win_w}')
+    assert np.array_equal(disp, odisp)
+    assert_surface_close(val, oval, 1e-12, 'band values')
+    disp, val = b.band_scan(left, right, win_w, win_h, 11, correlation_threshold=0.6)
+    odisp, oval = oracle.band_scan(left, right, win_w, win_h, 11, mode='fold', threshold=0.6)
+    assert np.array_equal(disp, odisp)
+    assert_surface_close(val, oval, 1e-12, 'band fold values')
 
 
 def test_band_scan_takes_the_loaders_output(mods):
@@ -958,7 +978,10 @@ def smooth_float_pair(h, w, seed, shift, contrast=1.0, offset=0.0):
 
 
 @pytest.mark.parametrize('win,h,w,md,stride', [(31, 80, 420, 24, 1), (25, 70, 300, 40, 2), (12, 40, 280, 9, 1),
-                                               (9, 33, 90, 5, 1)])
+                                               (9, 33, 90, 5, 1), (20, 50, 200, 14, 1), (24, 60, 330, 8, 2),
+                                               (5, 30, 100, 6, 1), (7, 30, 100, 6, 1), (10, 30, 150, 6, 1),
+                                               (11, 30, 100, 6, 2), (15, 40, 100, 6, 1), (16, 40, 100, 6, 1),
+                                               (21, 40, 130, 6, 1), (13, 40, 130, 6, 1)])
 def test_band_scan_float_images_vs_oracle(mods, oracle, win, h, w, md, stride):
     '''Floating-point images (no 8-bit levels: what downsample() returns for factors above
     1) through svamd_band_scan_f64: disparities exactly as the float64 oracle in both
