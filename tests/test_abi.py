@@ -27,6 +27,7 @@ def test_header_declares_expected_entry_points():
 def test_library_exports_every_declared_symbol():
     path = os.path.join(PKG, 'libsvamd.so')
     assert os.path.exists(path), 'libsvamd.so not built (make -C stereo-vision_amd)'
+    import torch  # noqa: F401  (first, as a host must: the library then binds to the HIP runtime PyTorch ships)
     lib = ctypes.CDLL(path)
     for name in declared_symbols():
         assert hasattr(lib, name), f'{name} declared in svamd.h but not exported'
