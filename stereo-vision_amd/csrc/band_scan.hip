@@ -822,10 +822,15 @@ band_collect_close_kernel(const double *__restrict__ margin, int nwx, int row_be
 
 // The windows on the list once more, every offset in float64 straight from the images,
 // then the same selection.  One wavefront per window: the centred left window sits in
-// LDS, a lane owns OPL consecutive offsets and slides a ring of OPL right-image values
-// along each row (one load and one LDS read per OPL multiply-adds).  The window
+// LDS; the right image's row segment under all offsets (nd + win_w - 1 columns) is staged
+// in LDS a row ahead (coalesced loads held in registers while the current row is worked
+// on; staging the left rows the same way instead of the whole window measured slower);
+// a lane owns OPL consecutive offsets and slides a ring of OPL right values along the
+// row (two LDS reads per OPL multiply-adds, no global load in the loop).  The window
 // statistics are the tables' (float64 already); only the cross term differs from the
 // first look.
+constexpr int RECHECK_AHEAD = 6;      // staged values a lane holds in registers: 384 columns; beyond, loaded in place
+
 template <int OPL>
 __global__ void __launch_bounds__(WAVE)
 band_recheck_kernel(BandGeom g, const double *__restrict__ left, const double *__restrict__ right,
@@ -836,8 +841,10 @@ band_recheck_kernel(BandGeom g, const double *__restrict__ left, const double *_
                     double *__restrict__ out_val, double *__restrict__ scores)
 {
     extern __shared__ __align__(16) double recheck_lds[];
+    const int seg = g.nd + g.win_w - 1;               // right columns under the window at all offsets
+    const int segp = (seg + OPL + 1) & ~1;            // + the ring's reach past the last offset
     double *Lw = recheck_lds;                         // win_h x win_w, centred
-    double *sc = recheck_lds + g.win_w * g.win_h;     // nd scores
+    double *Rs = Lw + ((g.win_w * g.win_h + 1) & ~1); // two staged row segments of segp values
     const int lane = threadIdx.x;
     const double centre_l = image_stats[0].mean, centre_r = image_stats[1].mean;
     const double n = (double)(g.win_w * g.win_h);
@@ -848,86 +855,187 @@ band_recheck_kernel(BandGeom g, const double *__restrict__ left, const double *_
         const int y = wy * g.stride_y;
         const int64_t srow = (int64_t)y * g.nsx;
         const double s1l = wsum_l[srow + wx], invl = winv_l[srow + wx];
+        const int x0 = wx - g.max_disp;                       // image column of the segment's first value
+        // columns outside the image are read at the border: they only reach offsets whose
+        // box leaves the image, and those are discarded below
+        auto fetch = [&](int r, double (&held)[RECHECK_AHEAD]) {
+            const double *rrow = right + (int64_t)(y + r) * g.W;
+#pragma unroll
+            for (int u = 0; u < RECHECK_AHEAD; ++u) {
+                const int i = lane + u * WAVE;
+                held[u] = i < segp ? rrow[min(max(x0 + i, 0), g.W - 1)] : 0.0;
+            }
+        };
+        auto stage = [&](int r, int buf, const double (&held)[RECHECK_AHEAD]) {
+            double *dst = Rs + buf * segp;
+#pragma unroll
+            for (int u = 0; u < RECHECK_AHEAD; ++u) {
+                const int i = lane + u * WAVE;
+                if (i < segp)
+                    dst[i] = held[u] - centre_r;
+            }
+            const double *rrow = right + (int64_t)(y + r) * g.W;
+            for (int i = lane + RECHECK_AHEAD * WAVE; i < segp; i += WAVE)
+                dst[i] = rrow[min(max(x0 + i, 0), g.W - 1)] - centre_r;
+        };
+        double held[RECHECK_AHEAD];
+        fetch(0, held);
         __syncthreads();                       // the previous window's LDS contents have been read
+        // (row = i / win_w by a multiply: exact for i * win_w < 2^32, and i < 4096 here)
+        const uint32_t inv_w = (uint32_t)((((uint64_t)1 << 32) + g.win_w - 1) / g.win_w);
+        const double *lwin = left + (int64_t)y * g.W + wx;
+#pragma unroll 4
         for (int i = lane; i < g.win_w * g.win_h; i += WAVE) {
-            const int r = i / g.win_w, c = i - r * g.win_w;
-            Lw[i] = left[(int64_t)(y + r) * g.W + wx + c] - centre_l;
+            const int r = (int)__umulhi((uint32_t)i, inv_w), c = i - r * g.win_w;
+            Lw[i] = lwin[r * g.W + c] - centre_l;
         }
+        stage(0, 0, held);
         __syncthreads();
         const int k_first = lane * OPL;                       // this lane's first offset index
-        const int x_first = wx + k_first - g.max_disp;        // ... and its box's first column
+        const int x_first = x0 + k_first;                     // ... and its box's first column
         double acc[OPL];
 #pragma unroll
         for (int j = 0; j < OPL; ++j)
             acc[j] = 0.0;
-        if (k_first < g.nd) {
-            for (int r = 0; r < g.win_h; ++r) {
-                const double *rrow = right + (int64_t)(y + r) * g.W;
+        for (int r = 0; r < g.win_h; ++r) {
+            if (r + 1 < g.win_h)
+                fetch(r + 1, held);
+            if (k_first < g.nd) {
+                const double *rr = Rs + (r & 1) * segp + k_first;
                 const double *lrow = Lw + r * g.win_w;
-                // columns outside the image are read at the border: they only reach offsets
-                // whose box leaves the image, and those are discarded below
-                auto pixel = [&](int x) { return rrow[min(max(x, 0), g.W - 1)] - centre_r; };
                 double ring[OPL];                             // R[c + j] lives in slot (c + j) % OPL
 #pragma unroll
                 for (int j = 0; j + 1 < OPL; ++j)
-                    ring[j] = pixel(x_first + j);
-                for (int c0 = 0; c0 < g.win_w; c0 += OPL) {
+                    ring[j] = rr[j];
+                // whole chunks of OPL columns, the next chunk's 2 OPL values read from LDS while
+                // this chunk's OPL x OPL multiply-adds run (one wait per chunk)
+                const int whole = g.win_w / OPL * OPL;
+                double lv[OPL], nv[OPL], lv2[OPL], nv2[OPL];
+                auto read_chunk = [&](int c0, double (&l)[OPL], double (&v)[OPL]) {
 #pragma unroll
                     for (int u = 0; u < OPL; ++u) {
-                        const int c = c0 + u;
-                        if (c < g.win_w) {                    // wave-uniform
-                            ring[(u + OPL - 1) % OPL] = pixel(x_first + c + OPL - 1);
-                            const double l = lrow[c];
+                        l[u] = lrow[c0 + u];
+                        v[u] = rr[c0 + u + OPL - 1];
+                    }
+                };
+                auto work_chunk = [&](const double (&l)[OPL], const double (&v)[OPL]) {
 #pragma unroll
-                            for (int j = 0; j < OPL; ++j)
-                                acc[j] = fma(l, ring[(u + j) % OPL], acc[j]);
-                        }
+                    for (int u = 0; u < OPL; ++u) {
+                        ring[(u + OPL - 1) % OPL] = v[u];
+#pragma unroll
+                        for (int j = 0; j < OPL; ++j)
+                            acc[j] = fma(l[u], ring[(u + j) % OPL], acc[j]);
+                    }
+                };
+                int c0 = 0;
+                if (whole > 0)
+                    read_chunk(0, lv, nv);
+                for (; c0 + 2 * OPL <= whole; c0 += 2 * OPL) {
+                    read_chunk(c0 + OPL, lv2, nv2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    work_chunk(lv, nv);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (c0 + 2 * OPL < whole)
+                        read_chunk(c0 + 2 * OPL, lv, nv);
+                    __builtin_amdgcn_sched_barrier(0);
+                    work_chunk(lv2, nv2);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (c0 < whole) {
+                    work_chunk(lv, nv);
+                    c0 += OPL;
+                }
+                // the columns left over (win_w is not a multiple of OPL)
+#pragma unroll
+                for (int u = 0; u < OPL; ++u) {
+                    const int c = c0 + u;
+                    if (c < g.win_w) {                        // wave-uniform
+                        ring[(u + OPL - 1) % OPL] = rr[c + OPL - 1];
+                        const double l = lrow[c];
+#pragma unroll
+                        for (int j = 0; j < OPL; ++j)
+                            acc[j] = fma(l, ring[(u + j) % OPL], acc[j]);
                     }
                 }
             }
+            if (r + 1 < g.win_h)
+                stage(r + 1, (r + 1) & 1, held);
+            __syncthreads();
         }
+        // scores stay in the lanes' registers; invalid ones (box outside the image) are NaN
+        double s[OPL];
 #pragma unroll
         for (int j = 0; j < OPL; ++j) {
             const int k = k_first + j;
-            if (k >= g.nd)
-                continue;
             const int xr = x_first + j;
-            double s = NAN;
-            if (xr >= 0 && xr < g.nsx)
-                s = fma(n, acc[j], -(s1l * wsum_r[srow + xr])) * invl * winv_r[srow + xr];
-            sc[k] = s;
-            if (scores)
-                scores[o * g.nd + k] = s;
+            s[j] = NAN;
+            if (k < g.nd && xr >= 0 && xr < g.nsx)
+                s[j] = fma(n, acc[j], -(s1l * wsum_r[srow + xr])) * invl * winv_r[srow + xr];
+            if (scores && k < g.nd)
+                scores[o * g.nd + k] = s[j];
         }
-        __syncthreads();
-        if (lane == 0) {
-            double best;
-            int arg;
-            if (g.mode == SVAMD_BAND_ARGMAX) {
-                best = -INFINITY;
+        double best;
+        int arg;
+        if (g.mode == SVAMD_BAND_ARGMAX) {
+            // first maximum in offset order: within the lane, then across lanes (ties to the lower offset)
+            best = -INFINITY;
+            arg = 0x7fffffff;
+#pragma unroll
+            for (int j = 0; j < OPL; ++j)
+                if (s[j] > best) {
+                    best = s[j];
+                    arg = k_first + j;
+                }
+#pragma unroll
+            for (int m = 1; m < WAVE; m <<= 1) {
+                const double ob = __shfl_xor(best, m);
+                const int oa = __shfl_xor(arg, m);
+                if (ob > best || (ob == best && oa < arg)) {
+                    best = ob;
+                    arg = oa;
+                }
+            }
+            if (arg == 0x7fffffff) {
+                best = NAN;
                 arg = SVAMD_BAND_NO_MATCH;
-                for (int k = 0; k < g.nd; ++k)
-                    if (sc[k] > best) {
-                        best = sc[k];
-                        arg = k - g.max_disp;
-                    }
-                if (arg == SVAMD_BAND_NO_MATCH)
-                    best = NAN;
             } else {
-                best = 0.0;
-                arg = 0;
-                const double c = sc[g.max_disp];
-                if (c > g.thr && c >= best)
-                    best = c;
-                for (int k = 0; k < g.nd; ++k) {
-                    if (k == g.max_disp)
-                        continue;
-                    if (sc[k] > g.thr && sc[k] > best + g.tol) {
-                        best = sc[k];
+                arg -= g.max_disp;
+            }
+        } else {
+            // image_scan's rule walks the offsets in order and moves on each candidate that beats
+            // the threshold and the running best by more than the tolerance.  Every lane replays
+            // the walk over the lanes' blocks; a block whose largest eligible score cannot beat
+            // the running best is passed over whole.
+            double centre_score = NAN, block_max = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < OPL; ++j) {
+                const int k = k_first + j;
+                if (k == g.max_disp)
+                    centre_score = s[j];
+                else if (s[j] > g.thr && s[j] > block_max)
+                    block_max = s[j];
+            }
+            best = 0.0;
+            arg = 0;
+            const double c = __shfl(centre_score, g.max_disp / OPL);
+            if (c > g.thr && c >= best)
+                best = c;
+            const int blocks = (g.nd + OPL - 1) / OPL;
+            for (int b = 0; b < blocks; ++b) {
+                if (!(__shfl(block_max, b) > best + g.tol))
+                    continue;                                  // wave-uniform
+#pragma unroll
+                for (int j = 0; j < OPL; ++j) {
+                    const double v = __shfl(s[j], b);
+                    const int k = b * OPL + j;
+                    if (k != g.max_disp && v > g.thr && v > best + g.tol) {
+                        best = v;
                         arg = k - g.max_disp;
                     }
                 }
             }
+        }
+        if (lane == 0) {
             out_disp[o] = arg;
             out_val[o] = best;
         }
@@ -1314,8 +1422,10 @@ extern "C" int svamd_band_scan_f64(const double *left, const double *right, int 
                        g.nwx, row_begin, row_end, guard_band, t.list, t.count);
     SV_LAUNCH_CHECK();
     const unsigned rgrid = (unsigned)(total < 32768 ? total : 32768);
-    const size_t rlds = ((size_t)win_w * win_h + g.nd) * sizeof(double);
     const int opl = (g.nd + WAVE - 1) / WAVE;                 // offsets per lane of the second look
+    // the window and two staged right-row segments (as band_recheck_kernel lays them out)
+    const size_t rsegp = (size_t)((g.nd + win_w - 1 + opl + 1) & ~1);
+    const size_t rlds = ((size_t)((win_w * win_h + 1) & ~1) + 2 * rsegp) * sizeof(double);
     SV_REQUIRE(opl <= 8 && rlds <= 60 * 1024, SVAMD_ERR_LIMIT,
                "band_scan_f64: %d offsets are more than the float64 second look handles (512)", g.nd);
 #define SV_RECHECK_CASE(N)                                                                                     \
