@@ -56,6 +56,9 @@ extern "C" {
 
 /* flags of svamd_band_scan_u8 */
 #define SVAMD_BAND_PREPARED 1   /* the workspace already holds svamd_band_prepare_u8's tables */
+#define SVAMD_BAND_BOX_SUMS 2   /* svamd_band_scan_u8: cross terms from per-offset summed-area tables of the
+                                   product image instead of one multiply-add per window pixel; identical
+                                   results (svamd_band_box_sums_supported says whether a shape fits) */
 
 int svamd_version(void);
 const char *svamd_last_error(void);
@@ -242,6 +245,10 @@ int svamd_scan_grid(const double *left, int64_t left_pitch, const double *right,
  * rows for narrow windows).  Window widths 3 ... 32 each have a fully unrolled kernel;
  * any other width runs through a kernel that takes it at run time. */
 size_t svamd_band_scan_u8_workspace_bytes(int H, int W, int win_w, int win_h);
+/* 1 when svamd_band_scan_u8 can run this window / row stride / offset range with
+ * SVAMD_BAND_BOX_SUMS (a tile's tables and the right band under all offsets must fit the
+ * LDS; win_w <= 257), else 0.  No counterpart in the reference. */
+int svamd_band_box_sums_supported(int win_w, int win_h, int stride_y, int max_disp);
 
 /* K1 for the band scan: summed-area tables of both images and, from them, the
  * per-position window sums and inverse deviations, into the workspace. */

@@ -21,6 +21,7 @@ ACC_F32, ACC_F64, ACC_MIXED = 0, 1, 2
 BAND_ARGMAX, BAND_FOLD = 0, 1
 BAND_NO_MATCH = -2 ** 31
 BAND_PREPARED = 1
+BAND_BOX_SUMS = 2
 PAIR_MAX_SIDE = 64
 
 _vp = ctypes.c_void_p
@@ -53,6 +54,7 @@ PROTOTYPES = {
     'svamd_scan_grid': (_i, [_vp, _i64, _vp, _i64, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i64,
                              _i, _d, _d, _d, _d, _i, _d, _vp, _vp, _vp, _sz, _vp]),
     'svamd_band_scan_u8_workspace_bytes': (_sz, [_i, _i, _i, _i]),
+    'svamd_band_box_sums_supported': (_i, [_i, _i, _i, _i]),
     'svamd_band_prepare_u8': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     'svamd_band_scan_u8': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _d, _d, _i, _i, _i,
                                 _vp, _vp, _vp, _vp, _sz, _vp]),

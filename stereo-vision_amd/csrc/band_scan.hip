@@ -1108,6 +1108,13 @@ extern "C" size_t svamd_band_scan_u8_workspace_bytes(int H, int W, int win_w, in
     return 4 * align_up(b.n_sat * 4, 256) + 2 * align_up(b.n_stat * 4, 256) + 2 * align_up(b.n_stat * 8, 256);
 }
 
+extern "C" int svamd_band_box_sums_supported(int win_w, int win_h, int stride_y, int max_disp)
+{
+    if (win_w <= 0 || win_h <= 0 || stride_y <= 0 || max_disp < 0 || (int64_t)win_w * win_h > 1024)
+        return 0;
+    return band_sums_fits(win_w, win_h, stride_y, max_disp) ? 1 : 0;
+}
+
 namespace {
 struct BandTables {
     uint32_t *s1l, *s2l, *s1r, *s2r;
@@ -1216,6 +1223,10 @@ extern "C" int svamd_band_scan_u8(const uint8_t *left, const uint8_t *right, int
     BandTables t = band_tables(workspace, H, W, win_w, win_h);
     const int32_t *wl = t.wl, *wr = t.wr;
     const double *il = t.il, *ir = t.ir;
+
+    if (flags & SVAMD_BAND_BOX_SUMS)
+        return band_sums_launch(left, right, H, W, win_w, win_h, stride_y, max_disp, mode, threshold, centre_tol,
+                                row_begin, row_end, wl, il, wr, ir, out_disp, out_val, scores, st);
 
     dim3 grid((g.nwx + BAND_TX - 1) / BAND_TX, (row_end - row_begin + g.tile_wrows - 1) / g.tile_wrows);
 #define SV_BAND_CASE(WW)                                                                          \

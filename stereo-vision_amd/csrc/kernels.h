@@ -64,4 +64,14 @@ int launch_pairs(const double *tbase, const double *rbase, const int64_t *desc, 
                  double *surfaces, const int64_t *surf_off, const int32_t *list, const int32_t *list_count,
                  unsigned list_grid, hipStream_t st);
 
+// band_sums.hip
+// svamd_band_scan_u8's scan by box sums of the per-offset product images (same tables, same
+// results as the multiply-add kernel).  band_sums_fits: whether a tile of this window and
+// offset range fits the LDS.
+bool band_sums_fits(int win_w, int win_h, int stride_y, int max_disp);
+int band_sums_launch(const uint8_t *left, const uint8_t *right, int H, int W, int win_w, int win_h, int stride_y,
+                     int max_disp, int mode, double thr, double tol, int row_begin, int row_end,
+                     const int32_t *wl, const double *il, const int32_t *wr, const double *ir, int32_t *out_disp,
+                     double *out_val, double *scores, hipStream_t st);
+
 }  // namespace svamd

@@ -906,6 +906,34 @@ def test_band_scan_every_unrolled_width(mods, oracle, win_w):
     assert_surface_close(val, oval, 1e-12, 'band fold values')
 
 
+@pytest.mark.parametrize('ww,wh,h,w,md,stride', [(31, 31, 70, 300, 24, 1), (31, 31, 47, 140, 128, 1),
+                                                 (15, 15, 40, 90, 10, 1), (7, 9, 33, 64, 5, 1), (12, 12, 90, 530, 17, 1),
+                                                 (25, 25, 120, 600, 9, 2), (20, 24, 75, 270, 40, 3), (5, 60, 90, 280, 6, 1),
+                                                 (32, 32, 64, 64, 8, 1), (1, 1, 9, 40, 3, 1)])
+def test_band_scan_box_sums_vs_oracle_and_products(mods, oracle, ww, wh, h, w, md, stride):
+    """The box-sum kernel (per-offset summed-area tables of the product image): score volume,
+    disparities and selection against the oracle, and every output equal bit for bit to
+    the multiply-add kernel's, in both selection modes."""
+    left, right = synthetic_pair(h, w, ww * 100 + wh + md, min(md, 12))
+    left[5:5 + wh, 3:3 + ww] = 200                       # a constant window
+    b = mods['b']
+    disp, val, scores = b.band_scan(left, right, ww, wh, md, row_stride=stride, want_scores=True, method='sums')
+    odisp, oval, oscores = oracle.band_scan(left, right, ww, wh, md, stride_y=stride, want_scores=True)
+    assert_surface_close(scores, oscores, 1e-12, 'box-sum band scores')
+    assert np.array_equal(disp, odisp)
+    assert_surface_close(val, oval, 1e-12, 'box-sum band values')
+    pdisp, pval, pscores = b.band_scan(left, right, ww, wh, md, row_stride=stride, want_scores=True)
+    assert np.array_equal(disp, pdisp) and np.array_equal(val, pval, equal_nan=True)
+    assert np.array_equal(scores, pscores, equal_nan=True)
+    for thr in (0.0, 0.6):
+        disp, val = b.band_scan(left, right, ww, wh, md, correlation_threshold=thr, row_stride=stride, method='sums')
+        odisp, oval = oracle.band_scan(left, right, ww, wh, md, stride_y=stride, mode='fold', threshold=thr)
+        assert np.array_equal(disp, odisp)
+        assert_surface_close(val, oval, 1e-12, 'box-sum band fold values')
+        pdisp, pval = b.band_scan(left, right, ww, wh, md, correlation_threshold=thr, row_stride=stride)
+        assert np.array_equal(disp, pdisp) and np.array_equal(val, pval, equal_nan=True)
+
+
 def test_band_scan_takes_the_loaders_output(mods):
     '''`downsample(image, 1)` scales 8-bit levels by the product with 1 / 255 (not the
     quotient by 255); the band scan recognises both and scans the same integers.'''
