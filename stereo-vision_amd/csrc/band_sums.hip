@@ -18,6 +18,8 @@
 //   B  a thread per table column adds the rows up;
 //   C  a thread per 8 (or 4) windows: four table reads, the right window's statistics from
 //      global memory, the score in float64, the selection kept in registers.
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -39,6 +41,7 @@ struct SumsGeom {
     double thr, tol;
     int row_begin, row_end;
     int tr;                // image rows of a tile
+    int rows_a;            // ... per wavefront in phase A
     int lanes_a;           // lanes of phase A that hold product columns
     int lpitch, rpitch;    // bytes per staged row of the left / right tile
     int spitch;            // table entries per row: 3 unused, the zero column, then the product columns
@@ -60,6 +63,20 @@ __device__ __forceinline__ uint32_t wave_prefix_u32(uint32_t v)
 
 __device__ __forceinline__ uint32_t byte_of(uint32_t w, int i) { return (w >> (8 * i)) & 0xffu; }
 
+// Diagnostic build only (-DSVAMD_SUMS_STAMPS, see profiles/stamp_sums.py): `scores` is taken
+// as eight 64-bit counters to which lane 0 of every wavefront adds the clocks it spent in
+// each phase (no scores are written).
+#ifdef SVAMD_SUMS_STAMPS
+#define SUMS_STAMP(slot)                                        \
+    do {                                                        \
+        const long long now_ = clock64();                       \
+        stamp_acc_[slot] += now_ - stamp_last_;                 \
+        stamp_last_ = now_;                                     \
+    } while (0)
+#else
+#define SUMS_STAMP(slot) do { } while (0)
+#endif
+
 // RPT: window rows per thread (tile = 16 * RPT window rows).
 template <int RPT>
 __global__ void __launch_bounds__(SUMS_THREADS)
@@ -70,7 +87,8 @@ band_sums_kernel(SumsGeom g, const uint8_t *__restrict__ left, const uint8_t *__
 {
     extern __shared__ __align__(16) uint32_t sums_lds[];
     uint32_t *sat = sums_lds;                                         // (tr + 1) x spitch
-    uint8_t *Lb = reinterpret_cast<uint8_t *>(sat + (g.tr + 1) * g.spitch);   // tr x lpitch
+    uint32_t *carry = sat + (g.tr + 1) * g.spitch;                    // one row per block of rows_a image rows
+    uint8_t *Lb = reinterpret_cast<uint8_t *>(carry + SUMS_WAVES * g.spitch);  // tr x lpitch
     uint8_t *Rb = Lb + g.tr * g.lpitch;                               // tr x rpitch
 
     const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
@@ -97,12 +115,13 @@ band_sums_kernel(SumsGeom g, const uint8_t *__restrict__ left, const uint8_t *__
     // ---- the windows of this thread: rows wave, wave + 16; columns lane, lane + 64, ...
     constexpr int NW = RPT * SUMS_COLS_PER_THREAD;
     double best[NW], invl[NW];
-    int arg[NW], s1l[NW];
+    int arg[NW], s1l[NW], r_first[RPT];
     const double n = (double)(g.win_w * g.win_h);
 #pragma unroll
     for (int rr = 0; rr < RPT; ++rr) {
         const int wy = wy0 + wave + SUMS_WAVES * rr;
         const int64_t srow = (int64_t)min(wy, g.row_end - 1) * g.stride_y * g.nsx;
+        r_first[rr] = (int)srow;                                      // (the tables hold fewer than 2^31 entries)
 #pragma unroll
         for (int j = 0; j < SUMS_COLS_PER_THREAD; ++j) {
             const int w = rr * SUMS_COLS_PER_THREAD + j;
@@ -115,6 +134,12 @@ band_sums_kernel(SumsGeom g, const uint8_t *__restrict__ left, const uint8_t *__
     }
     __syncthreads();
 
+#ifdef SVAMD_SUMS_STAMPS
+    long long stamp_acc_[8] = {}, stamp_last_ = clock64();
+    double *scores_out = nullptr;
+#else
+    double *scores_out = scores;
+#endif
     // selection-rule mode judges the centre offset first, then all others in ascending order
     const int steps = g.mode == SVAMD_BAND_FOLD ? g.nd + 1 : g.nd;
     for (int it = 0; it < steps; ++it) {
@@ -127,51 +152,103 @@ band_sums_kernel(SumsGeom g, const uint8_t *__restrict__ left, const uint8_t *__
                 continue;                                             // uniform over the workgroup
         }
 
-        // ---- phase A: row sums of the products of offset index k (right column = left column + k)
+        SUMS_STAMP(0);      // loop head, barrier wait of the previous step
+        const double thr_k = g.mode == SVAMD_BAND_FOLD ? g.thr : -INFINITY;
+        const double tol_k = g.mode == SVAMD_BAND_FOLD && !centre_rule ? g.tol : 0.0;
+        // ---- phase A: a wavefront owns a block of consecutive image rows and leaves the
+        // block's own two-dimensional prefix sums of the products of offset index k (right
+        // column = left column + k): a row's running sums plus the block's rows above it
         const int shift = k & 3;
-        for (int y = wave; y < g.tr; y += SUMS_WAVES) {
-            uint32_t p[SUMS_CPL];
-            if (lane < g.lanes_a) {
-                const uint2 lw = *reinterpret_cast<const uint2 *>(Lb + y * g.lpitch + SUMS_CPL * lane);
-                const uint32_t *rw = reinterpret_cast<const uint32_t *>(Rb + y * g.rpitch + SUMS_CPL * lane + (k & ~3));
+        {
+            uint32_t above[SUMS_CPL];
+#pragma unroll
+            for (int i = 0; i < SUMS_CPL; ++i)
+                above[i] = 0;
+            const int y_end = min((wave + 1) * g.rows_a, g.tr);
+            for (int y = wave * g.rows_a; y < y_end; ++y) {
+                // (lanes without columns read the last lane's bytes and multiply by zero: no branch)
+                uint32_t p[SUMS_CPL];
+                const int la = min(lane, g.lanes_a - 1);
+                uint2 lw = *reinterpret_cast<const uint2 *>(Lb + y * g.lpitch + SUMS_CPL * la);
+                lw.x = lane < g.lanes_a ? lw.x : 0u;
+                lw.y = lane < g.lanes_a ? lw.y : 0u;
+                const uint32_t *rw =
+                    reinterpret_cast<const uint32_t *>(Rb + y * g.rpitch + SUMS_CPL * la + (k & ~3));
                 const uint32_t r0 = rw[0], r1 = rw[1], r2 = rw[2];
                 const uint32_t ra = __builtin_amdgcn_alignbyte(r1, r0, shift);
                 const uint32_t rb = __builtin_amdgcn_alignbyte(r2, r1, shift);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    p[i] = byte_of(lw.x, i) * byte_of(ra, i);
-                    p[4 + i] = byte_of(lw.y, i) * byte_of(rb, i);
-                }
-            } else {
+                // running sums of the four byte products of a word: dot products with the
+                // left bytes masked off from the top
+                p[0] = __builtin_amdgcn_udot4(lw.x & 0xffu, ra, 0u, false);
+                p[1] = __builtin_amdgcn_udot4(lw.x & 0xffffu, ra, 0u, false);
+                p[2] = __builtin_amdgcn_udot4(lw.x & 0xffffffu, ra, 0u, false);
+                p[3] = __builtin_amdgcn_udot4(lw.x, ra, 0u, false);
+                p[4] = __builtin_amdgcn_udot4(lw.y & 0xffu, rb, p[3], false);
+                p[5] = __builtin_amdgcn_udot4(lw.y & 0xffffu, rb, p[3], false);
+                p[6] = __builtin_amdgcn_udot4(lw.y & 0xffffffu, rb, p[3], false);
+                p[7] = __builtin_amdgcn_udot4(lw.y, rb, p[3], false);
+                const uint32_t before = wave_prefix_u32(p[SUMS_CPL - 1]) - p[SUMS_CPL - 1];
 #pragma unroll
                 for (int i = 0; i < SUMS_CPL; ++i)
-                    p[i] = 0;
+                    above[i] += p[i] + before;
+                if (lane < g.lanes_a) {
+                    uint4 *dst = reinterpret_cast<uint4 *>(sat + (y + 1) * g.spitch + 4 + SUMS_CPL * lane);
+                    dst[0] = uint4{above[0], above[1], above[2], above[3]};
+                    dst[1] = uint4{above[4], above[5], above[6], above[7]};
+                }
             }
-#pragma unroll
-            for (int i = 1; i < SUMS_CPL; ++i)
-                p[i] += p[i - 1];
-            const uint32_t before = wave_prefix_u32(p[SUMS_CPL - 1]) - p[SUMS_CPL - 1];
-            if (lane < g.lanes_a) {
-                uint4 *dst = reinterpret_cast<uint4 *>(sat + (y + 1) * g.spitch + 4 + SUMS_CPL * lane);
-                dst[0] = uint4{p[0] + before, p[1] + before, p[2] + before, p[3] + before};
-                dst[1] = uint4{p[4] + before, p[5] + before, p[6] + before, p[7] + before};
+        }
+        SUMS_STAMP(1);      // phase A
+        __syncthreads();
+        SUMS_STAMP(2);      // waiting for the others' phase A
+
+        // ---- phase B: what the blocks above a block add to each of its columns (a thread per
+        // column walks the blocks' last rows), then every entry takes its block's share
+        {
+            // sixteen lanes = the sixteen blocks of one column: a prefix sum within the rows
+            // of 16 lanes of the blocks' last table rows gives what each block hands down
+            const int ncols = SUMS_CPL * g.lanes_a, b = lane & 15;
+            for (int c = 4 * wave + (lane >> 4); c - (lane >> 4) < ncols; c += 4 * SUMS_WAVES) {
+                const bool has = c < ncols && (b + 1) * g.rows_a < g.tr;      // a block below takes it
+                uint32_t v = has ? sat[(b + 1) * g.rows_a * g.spitch + 4 + c] : 0u;
+                v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+                v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+                v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+                v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+                if (has)
+                    carry[(b + 1) * g.spitch + 4 + c] = v;
             }
         }
         __syncthreads();
-
-        // ---- phase B: down the columns
-        if ((int)threadIdx.x < SUMS_CPL * g.lanes_a) {
-            uint32_t *col = sat + 4 + threadIdx.x;
-            uint32_t run = 0;
-#pragma unroll 4
-            for (int r = 1; r <= g.tr; ++r) {
-                run += col[r * g.spitch];
-                col[r * g.spitch] = run;
+        SUMS_STAMP(3);      // block carries (and the wait for them)
+        {
+            // four entries of a row at a time; (row, quad) advance by the thread count without a division
+            const int quads = SUMS_CPL * g.lanes_a / 4;               // per row
+            const int dr = SUMS_THREADS / quads, dc = SUMS_THREADS - dr * quads;
+            const uint32_t inv_rows = (uint32_t)((((uint64_t)1 << 32) + g.rows_a - 1) / g.rows_a);   // r / rows_a by a multiply (r is small)
+            int r = g.rows_a + (int)threadIdx.x / quads, c = (int)threadIdx.x % quads;
+            while (r < g.tr) {
+                uint4 *e = reinterpret_cast<uint4 *>(sat + (r + 1) * g.spitch + 4 + 4 * c);
+                const int blk = (int)__umulhi((uint32_t)r, inv_rows);
+                const uint4 add = *reinterpret_cast<const uint4 *>(carry + blk * g.spitch + 4 + 4 * c);
+                uint4 v = *e;
+                v.x += add.x; v.y += add.y; v.z += add.z; v.w += add.w;
+                *e = v;
+                r += dr;
+                c += dc;
+                if (c >= quads) {
+                    c -= quads;
+                    ++r;
+                }
             }
         }
+        SUMS_STAMP(4);      // the entries' update
         __syncthreads();
+        SUMS_STAMP(5);      // waiting for the others' update
 
-        // ---- phase C: the windows' scores at this offset and the selection
+        // ---- phase C: the windows' scores at this offset and the selection (the variant that
+        // also writes the score volume is a separate copy of the loop)
+        auto phase_c = [&](auto with_scores) {
 #pragma unroll
         for (int rr = 0; rr < RPT; ++rr) {
             const int wrow = wave + SUMS_WAVES * rr;
@@ -180,43 +257,46 @@ band_sums_kernel(SumsGeom g, const uint8_t *__restrict__ left, const uint8_t *__
                 continue;                                             // wave-uniform
             const uint32_t *top = sat + wrow * g.stride_y * g.spitch + 3;
             const uint32_t *bot = top + g.win_h * g.spitch;
-            const int64_t srow = (int64_t)wy * g.stride_y * g.nsx;
 #pragma unroll
             for (int j = 0; j < SUMS_COLS_PER_THREAD; ++j) {
                 const int w = rr * SUMS_COLS_PER_THREAD + j;
                 const int x = lane + WAVE * j;
                 const int xw = x0 + x;
                 const int xr = xw + k - g.max_disp;                   // the right window's column
-                const bool wvalid = xw < g.nwx;
-                const bool in = xr >= 0 && xr < g.nsx;
-                const int xrc = min(max(xr, 0), g.nsx - 1);
-                const int rs = wsum_r[srow + xrc];
-                const double ri = winv_r[srow + xrc];
+                // (plain & and |: no branches; an invalid evaluation becomes NaN through its factor)
+                const bool valid = (xw < g.nwx) & (xr >= 0) & (xr < g.nsx);
+                const int at = r_first[rr] + min(max(xr, 0), g.nsx - 1);
+                const int rs = wsum_r[at];
+                const double r_inv_w = valid ? winv_r[at] : NAN;
                 // sum of L * R over the window, then of (L - 128)(R - 128): all exact integers
                 const uint32_t lr = bot[x + g.win_w] - top[x + g.win_w] - bot[x] + top[x];
                 const int cross = (int)lr - 128 * (s1l[w] + rs) - 16384 * g.win_w * g.win_h;
                 const double num = fma(n, (double)cross, -((double)s1l[w] * (double)rs));
-                const double s = (wvalid && in) ? num * invl[w] * ri : NAN;
-                if (scores && wvalid)
-                    scores[((int64_t)wy * g.nwx + xw) * g.nd + k] = s;
-                if (g.mode == SVAMD_BAND_ARGMAX) {
-                    if (s > best[w]) {
-                        best[w] = s;
-                        arg[w] = k - g.max_disp;
-                    }
-                } else if (centre_rule) {
-                    if (s > g.thr && s >= best[w]) {
-                        best[w] = s;
-                        arg[w] = 0;
-                    }
-                } else if (s > g.thr && s > best[w] + g.tol) {
-                    best[w] = s;
-                    arg[w] = k - g.max_disp;
+                const double s = num * invl[w] * r_inv_w;
+                if constexpr (decltype(with_scores)::value) {
+                    if (xw < g.nwx)
+                        scores_out[((int64_t)wy * g.nwx + xw) * g.nd + k] = s;
                 }
+                // one rule for both modes: arg-max is the rule without a threshold and a tolerance
+                const double lim = best[w] + tol_k;
+                const bool take = (s > thr_k) & ((s > lim) | (centre_rule & (s == lim)));
+                best[w] = take ? s : best[w];
+                arg[w] = take ? k - g.max_disp : arg[w];
             }
         }
+        };
+        if (scores_out)
+            phase_c(std::true_type{});
+        else
+            phase_c(std::false_type{});
+        SUMS_STAMP(6);      // phase C
         __syncthreads();                                              // the table is rebuilt for the next offset
     }
+#ifdef SVAMD_SUMS_STAMPS
+    if (scores && lane == 0)
+        for (int i = 0; i < 8; ++i)
+            atomicAdd(reinterpret_cast<unsigned long long *>(scores) + i, (unsigned long long)stamp_acc_[i]);
+#endif
 
 #pragma unroll
     for (int rr = 0; rr < RPT; ++rr) {
@@ -244,10 +324,11 @@ size_t sums_geometry(SumsGeom &g, int rpt)
     if (g.lanes_a > WAVE)
         return 0;
     g.tr = (SUMS_WAVES * rpt - 1) * g.stride_y + g.win_h;
+    g.rows_a = (g.tr + SUMS_WAVES - 1) / SUMS_WAVES;
     g.lpitch = SUMS_CPL * g.lanes_a;
     g.rpitch = (int)align_up((size_t)(g.lpitch + g.nd + 8), 8);        // phase A reads 12 bytes from column + (k & ~3)
     g.spitch = 4 + SUMS_CPL * g.lanes_a;
-    const size_t lds = (size_t)(g.tr + 1) * g.spitch * 4 + (size_t)g.tr * (g.lpitch + g.rpitch);
+    const size_t lds = (size_t)(g.tr + 1 + SUMS_WAVES) * g.spitch * 4 + (size_t)g.tr * (g.lpitch + g.rpitch);
     return lds <= (size_t)SUMS_LDS_LIMIT ? lds : 0;
 }
 
