@@ -19,8 +19,7 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 PHASES = ['loop head + wait for the slowest phase C', 'A: products, row and block prefix sums',
-          'wait for the slowest phase A', 'B1: block carries (5 wavefronts) + wait', 'B2: entries take their carries',
-          'wait for the slowest B2', 'C: scores and selection', '-']
+          'wait for the slowest phase A', 'B: block carries + wait for the slowest', '-', '-', 'C: scores and selection', '-']
 
 
 def main(path):

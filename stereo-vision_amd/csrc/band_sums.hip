@@ -111,6 +111,9 @@ band_sums_kernel(SumsGeom g, const uint8_t *__restrict__ left, const uint8_t *__
         sat[i] = 0;
     for (int r = threadIdx.x; r <= g.tr; r += SUMS_THREADS)
         sat[r * g.spitch + 3] = 0;
+    for (int i = threadIdx.x; i < SUMS_WAVES * g.spitch; i += SUMS_THREADS)
+        carry[i] = 0;                                                 // block 0 and the zero column take nothing
+    const uint32_t inv_rows = (uint32_t)((((uint64_t)1 << 32) + g.rows_a - 1) / g.rows_a);   // r / rows_a by a multiply (r is small)
 
     // ---- the windows of this thread: rows wave, wave + 16; columns lane, lane + 64, ...
     constexpr int NW = RPT * SUMS_COLS_PER_THREAD;
@@ -221,69 +224,52 @@ band_sums_kernel(SumsGeom g, const uint8_t *__restrict__ left, const uint8_t *__
         }
         __syncthreads();
         SUMS_STAMP(3);      // block carries (and the wait for them)
-        {
-            // four entries of a row at a time; (row, quad) advance by the thread count without a division
-            const int quads = SUMS_CPL * g.lanes_a / 4;               // per row
-            const int dr = SUMS_THREADS / quads, dc = SUMS_THREADS - dr * quads;
-            const uint32_t inv_rows = (uint32_t)((((uint64_t)1 << 32) + g.rows_a - 1) / g.rows_a);   // r / rows_a by a multiply (r is small)
-            int r = g.rows_a + (int)threadIdx.x / quads, c = (int)threadIdx.x % quads;
-            while (r < g.tr) {
-                uint4 *e = reinterpret_cast<uint4 *>(sat + (r + 1) * g.spitch + 4 + 4 * c);
-                const int blk = (int)__umulhi((uint32_t)r, inv_rows);
-                const uint4 add = *reinterpret_cast<const uint4 *>(carry + blk * g.spitch + 4 + 4 * c);
-                uint4 v = *e;
-                v.x += add.x; v.y += add.y; v.z += add.z; v.w += add.w;
-                *e = v;
-                r += dr;
-                c += dc;
-                if (c >= quads) {
-                    c -= quads;
-                    ++r;
-                }
-            }
-        }
-        SUMS_STAMP(4);      // the entries' update
-        __syncthreads();
-        SUMS_STAMP(5);      // waiting for the others' update
 
         // ---- phase C: the windows' scores at this offset and the selection (the variant that
         // also writes the score volume is a separate copy of the loop)
         auto phase_c = [&](auto with_scores) {
 #pragma unroll
-        for (int rr = 0; rr < RPT; ++rr) {
-            const int wrow = wave + SUMS_WAVES * rr;
-            const int wy = wy0 + wrow;
-            if (wy >= g.row_end)
-                continue;                                             // wave-uniform
-            const uint32_t *top = sat + wrow * g.stride_y * g.spitch + 3;
-            const uint32_t *bot = top + g.win_h * g.spitch;
+            for (int rr = 0; rr < RPT; ++rr) {
+                const int wrow = wave + SUMS_WAVES * rr;
+                const int wy = wy0 + wrow;
+                if (wy >= g.row_end)
+                    continue;                                         // wave-uniform
+                const int ytop = wrow * g.stride_y, ybot = ytop + g.win_h;   // table rows of the window's corners
+                const uint32_t *top = sat + ytop * g.spitch + 3;
+                const uint32_t *bot = sat + ybot * g.spitch + 3;
+                // table row r holds image row r - 1, which lies in block (r - 1) / rows_a; row 0 is all zero
+                const uint32_t *ctop =
+                    carry + (ytop > 0 ? (int)__umulhi((uint32_t)(ytop - 1), inv_rows) : 0) * g.spitch + 3;
+                const uint32_t *cbot = carry + (int)__umulhi((uint32_t)(ybot - 1), inv_rows) * g.spitch + 3;
 #pragma unroll
-            for (int j = 0; j < SUMS_COLS_PER_THREAD; ++j) {
-                const int w = rr * SUMS_COLS_PER_THREAD + j;
-                const int x = lane + WAVE * j;
-                const int xw = x0 + x;
-                const int xr = xw + k - g.max_disp;                   // the right window's column
-                // (plain & and |: no branches; an invalid evaluation becomes NaN through its factor)
-                const bool valid = (xw < g.nwx) & (xr >= 0) & (xr < g.nsx);
-                const int at = r_first[rr] + min(max(xr, 0), g.nsx - 1);
-                const int rs = wsum_r[at];
-                const double r_inv_w = valid ? winv_r[at] : NAN;
-                // sum of L * R over the window, then of (L - 128)(R - 128): all exact integers
-                const uint32_t lr = bot[x + g.win_w] - top[x + g.win_w] - bot[x] + top[x];
-                const int cross = (int)lr - 128 * (s1l[w] + rs) - 16384 * g.win_w * g.win_h;
-                const double num = fma(n, (double)cross, -((double)s1l[w] * (double)rs));
-                const double s = num * invl[w] * r_inv_w;
-                if constexpr (decltype(with_scores)::value) {
-                    if (xw < g.nwx)
-                        scores_out[((int64_t)wy * g.nwx + xw) * g.nd + k] = s;
+                for (int j = 0; j < SUMS_COLS_PER_THREAD; ++j) {
+                    const int w = rr * SUMS_COLS_PER_THREAD + j;
+                    const int x = lane + WAVE * j;
+                    const int xw = x0 + x;
+                    const int xr = xw + k - g.max_disp;               // the right window's column
+                    // (plain & and |: an invalid evaluation becomes NaN through its factor)
+                    const bool valid = (xw < g.nwx) & (xr >= 0) & (xr < g.nsx);
+                    const int at = r_first[rr] + min(max(xr, 0), g.nsx - 1);
+                    const int rs = wsum_r[at];
+                    const double ri = valid ? winv_r[at] : NAN;
+                    // sum of L * R over the window (the table is block-local: each corner takes what
+                    // the blocks above its row add), then of (L - 128)(R - 128): all exact integers
+                    const uint32_t lr = (bot[x + g.win_w] - top[x + g.win_w] - bot[x] + top[x]) +
+                                        (cbot[x + g.win_w] - ctop[x + g.win_w] - cbot[x] + ctop[x]);
+                    const int cross = (int)lr - 128 * (s1l[w] + rs) - 16384 * g.win_w * g.win_h;
+                    const double num = fma(n, (double)cross, -((double)s1l[w] * (double)rs));
+                    const double s = num * invl[w] * ri;
+                    if constexpr (decltype(with_scores)::value) {
+                        if (xw < g.nwx)
+                            scores_out[((int64_t)wy * g.nwx + xw) * g.nd + k] = s;
+                    }
+                    // one rule for both modes: arg-max is the rule without a threshold and a tolerance
+                    const double lim = best[w] + tol_k;
+                    const bool take = (s > thr_k) & ((s > lim) | (centre_rule & (s == lim)));
+                    best[w] = take ? s : best[w];
+                    arg[w] = take ? k - g.max_disp : arg[w];
                 }
-                // one rule for both modes: arg-max is the rule without a threshold and a tolerance
-                const double lim = best[w] + tol_k;
-                const bool take = (s > thr_k) & ((s > lim) | (centre_rule & (s == lim)));
-                best[w] = take ? s : best[w];
-                arg[w] = take ? k - g.max_disp : arg[w];
             }
-        }
         };
         if (scores_out)
             phase_c(std::true_type{});
