@@ -381,6 +381,36 @@ def main():
         else:
             found = int((job.scanner.disp != 0).sum().item())
 
+    # secondary: the same scan through the box-sum kernel (identical results by construction and
+    # checked here), K1 + kernel per step, no gather
+    box = None
+    sc = job.scanner
+    if sc.box_sums_supported():
+        sc.run(THRESHOLD, prepared=False)
+        want_d, want_v = sc.disp.clone(), sc.val.clone()
+        sc.run(THRESHOLD, method='sums')
+        same = bool(torch.equal(sc.disp, want_d) and torch.equal(sc.val.view(torch.int64), want_v.view(torch.int64)))
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            sc.prepare()
+            sc.run(THRESHOLD, prepared=True, method='sums')
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        box_elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([box_elapsed, 0.0 if same else 1.0], dtype=torch.float64, device=wire)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            box_elapsed, same = float(t[0].item()), bool(t[1].item() == 0.0)
+        box = {'value': evals * args.steps / box_elapsed, 'unit': 'NCC window evals/s',
+               'ms_per_step': box_elapsed / args.steps * 1e3, 'identical_to_the_timed_kernel': same,
+               'what': 'the same scan with SVAMD_BAND_BOX_SUMS: cross terms from per-offset summed-area tables '
+                       'of the product image in LDS (tables + kernel per step, no gather); not the headline, '
+                       'whose metric counts one multiply-add per window pixel'}
+
     weak = None
     if world > 1 and not args.no_weak:
         # secondary: a pair of its own per rank (weak scaling), same step structure
@@ -431,6 +461,8 @@ def main():
         }
         if check is not None:
             line['config']['gathered_map_equals_single_gpu_scan'] = check
+        if box is not None:
+            line['box_sum_variant'] = box
         if weak is not None:
             line['scaling_weak_value'] = weak
             line['scaling_weak_note'] = f'{world} pairs per step, one per GPU, results gathered to rank 0'

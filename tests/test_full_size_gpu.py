@@ -90,6 +90,24 @@ def test_dense_scan_is_deterministic_and_shards(dense):
     assert np.array_equal(scanner.disp.cpu().numpy(), dense['fold'][0])
 
 
+def test_dense_scan_by_box_sums_is_identical(dense):
+    """The box-sum kernel (per-offset summed-area tables of the product image) on the whole
+    4096 x 4096 pair: disparities and correlations equal to the multiply-add kernel's bit
+    for bit, in both selection modes, and for a band of window rows as a rank would scan it."""
+    scanner = dense['scanner']
+    assert scanner.box_sums_supported()
+    scanner.run(THRESHOLD, method='sums')
+    assert np.array_equal(scanner.disp.cpu().numpy(), dense['fold'][0])
+    assert np.array_equal(scanner.val.cpu().numpy(), dense['fold'][1], equal_nan=True)
+    scanner.run(None, method='sums')
+    assert np.array_equal(scanner.disp.cpu().numpy(), dense['argmax'][0])
+    assert np.array_equal(scanner.val.cpu().numpy(), dense['argmax'][1], equal_nan=True)
+    scanner.disp.fill_(-9)
+    scanner.run(THRESHOLD, rows=(1355, 2711), method='sums')
+    assert np.array_equal(scanner.disp.cpu().numpy()[1355:2711], dense['fold'][0][1355:2711])
+    assert (scanner.disp.cpu().numpy()[:1355] == -9).all() and (scanner.disp.cpu().numpy()[2711:] == -9).all()
+
+
 def test_dense_scan_selection_rule_follows_from_the_argmax(dense):
     '''image_scan's rule keeps the centre unless a candidate beats both the
     threshold and the centre by more than the tolerance: wherever the plain
