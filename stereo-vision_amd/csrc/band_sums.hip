@@ -10,14 +10,20 @@
 // (sv_image_comparison.py:249-255) per window); svamd_band_scan_u8 takes this kernel when
 // asked to (SVAMD_BAND_BOX_SUMS).
 //
-// Workgroup = 16 wavefronts = a tile of 32 (or 16) window rows x 256 window columns.  Per
-// offset, three phases separated by barriers:
-//   A  a wavefront per image row: each lane multiplies 8 consecutive pixel pairs (bytes
-//      from LDS), prefixes them, the lanes' totals are scanned across the wavefront, and
-//      the row's running sums go to the table;
-//   B  a thread per table column adds the rows up;
-//   C  a thread per 8 (or 4) windows: four table reads, the right window's statistics from
-//      global memory, the score in float64, the selection kept in registers.
+// Workgroup = 16 wavefronts = a tile of 32 (or 16) window rows x 256 window columns; the
+// left tile and the right band under all offsets sit in LDS as bytes.  Per offset, three
+// phases separated by barriers:
+//   A  a wavefront owns a block of consecutive image rows: per row each lane forms the
+//      running sums of 8 consecutive pixel products (dot products of masked bytes), the
+//      lanes' totals are prefixed across the wavefront (DPP), and the row is added to the
+//      block's rows above it - the table a block writes is its own 2-D prefix sum;
+//   B  sixteen lanes per column prefix the blocks' last rows: each block's carry, i.e.
+//      what the blocks above it add to its columns;
+//   C  a thread per 8 (or 4) windows: four table corners and the four carries of their
+//      blocks, the right window's statistics from global memory, the score in float64,
+//      the selection kept in registers for the whole tile.
+// Integer arithmetic wraps around modulo 2^32; window sums are differences of table
+// entries and fit 32 bits, so they are exact.
 #include <type_traits>
 
 #include "common.h"
@@ -60,8 +66,6 @@ __device__ __forceinline__ uint32_t wave_prefix_u32(uint32_t v)
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
     return v;
 }
-
-__device__ __forceinline__ uint32_t byte_of(uint32_t w, int i) { return (w >> (8 * i)) & 0xffu; }
 
 // Diagnostic build only (-DSVAMD_SUMS_STAMPS, see profiles/stamp_sums.py): `scores` is taken
 // as eight 64-bit counters to which lane 0 of every wavefront adds the clocks it spent in
