@@ -1210,9 +1210,9 @@ extern "C" int svamd_band_scan_u8(const uint8_t *left, const uint8_t *right, int
     // kernel that takes the width at run time, which serves the wider windows)
     const bool tuned = win_w >= 3 && win_w <= 32;
     const size_t lds = band_tile_geometry(g, tuned);
-    SV_REQUIRE(lds > 0, SVAMD_ERR_LIMIT,
+    SV_REQUIRE(lds > 0 || (flags & SVAMD_BAND_BOX_SUMS), SVAMD_ERR_LIMIT,
                "band_scan_u8: window %dx%d with row stride %d does not fit the LDS tile", win_w, win_h,
-               stride_y);
+               stride_y);                          // (the box-sum kernel checks its own tile)
 
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (!(flags & SVAMD_BAND_PREPARED)) {

@@ -55,6 +55,11 @@ def test_argument_validation_needs_no_gpu():
     rc = lib.svamd_scan_pairs(one, one, one, 4, 65, 1e-4, 1e-9, 0, one, None, None, None, None)
     assert rc == _native.ERR_LIMIT
     assert lib.svamd_cross_correlate_2d_workspace_bytes(31, 31, 64, 64) > 0
+    # shape queries are host arithmetic
+    assert lib.svamd_band_box_sums_supported(31, 31, 1, 128) == 1
+    assert lib.svamd_band_box_sums_supported(5, 200, 1, 6) == 0        # the tile's rows do not fit the LDS
+    assert lib.svamd_band_box_sums_supported(31, 31, 1, 40000) == 0    # nor does a band this wide
+    assert lib.svamd_band_box_sums_supported(40, 40, 1, 8) == 0        # beyond the scan's window area
 
 
 def test_host_modules_fail_loudly_without_gpu():

@@ -1064,6 +1064,13 @@ def test_band_scan_rejects_unsupported(mods):
         b.band_scan(np.zeros((80, 80), np.uint8), np.zeros((80, 80), np.uint8), 33, 32, 3)
     with pytest.raises(mods['n'].NativeError, match='does not fit the LDS tile'):
         b.band_scan(np.zeros((230, 280), np.uint8), np.zeros((230, 280), np.uint8), 5, 200, 6)
+    # the box-sum kernel keeps a tile's table and the right band under all offsets in LDS
+    with pytest.raises(mods['n'].NativeError, match='does not fit the box-sum tile'):
+        b.band_scan(np.zeros((230, 280), np.uint8), np.zeros((230, 280), np.uint8), 5, 200, 6, method='sums')
+    with pytest.raises(mods['n'].NativeError, match='does not fit the box-sum tile'):
+        b.band_scan(np.zeros((64, 300), np.uint8), np.zeros((64, 300), np.uint8), 31, 31, 40000, method='sums')
+    with pytest.raises(ValueError):
+        b.band_scan(np.zeros((40, 40), np.uint8), np.zeros((40, 40), np.uint8), 7, 7, 3, method='fastest')
 
 
 @pytest.mark.parametrize('ww,wh,h,w,md,stride', [(8, 8, 40, 90, 10, 1), (12, 12, 50, 300, 17, 1), (25, 25, 60, 140, 9, 2),
