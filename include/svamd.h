@@ -247,7 +247,8 @@ int svamd_scan_grid(const double *left, int64_t left_pitch, const double *right,
 size_t svamd_band_scan_u8_workspace_bytes(int H, int W, int win_w, int win_h);
 /* 1 when svamd_band_scan_u8 can run this window / row stride / offset range with
  * SVAMD_BAND_BOX_SUMS (a tile's tables and the right band under all offsets must fit the
- * LDS; win_w <= 257), else 0.  No counterpart in the reference. */
+ * LDS; win_w <= 257; window area up to 4096, where the multiply-add kernel stops at
+ * 1024), else 0.  No counterpart in the reference. */
 int svamd_band_box_sums_supported(int win_w, int win_h, int stride_y, int max_disp);
 
 /* K1 for the band scan: summed-area tables of both images and, from them, the

@@ -1110,7 +1110,7 @@ extern "C" size_t svamd_band_scan_u8_workspace_bytes(int H, int W, int win_w, in
 
 extern "C" int svamd_band_box_sums_supported(int win_w, int win_h, int stride_y, int max_disp)
 {
-    if (win_w <= 0 || win_h <= 0 || stride_y <= 0 || max_disp < 0 || (int64_t)win_w * win_h > 1024)
+    if (win_w <= 0 || win_h <= 0 || stride_y <= 0 || max_disp < 0 || (int64_t)win_w * win_h > 4096)
         return 0;
     return band_sums_fits(win_w, win_h, stride_y, max_disp) ? 1 : 0;
 }
@@ -1145,8 +1145,8 @@ extern "C" int svamd_band_prepare_u8(const uint8_t *left, const uint8_t *right, 
     SV_REQUIRE(H > 0 && W > 0 && win_w > 0 && win_h > 0, SVAMD_ERR_INVALID, "band_prepare_u8: non-positive size");
     SV_REQUIRE(win_w <= W && win_h <= H, SVAMD_ERR_SHAPE,
                "Dimensions of template must not exceed those of region.");
-    SV_REQUIRE((int64_t)win_w * win_h <= 1024, SVAMD_ERR_LIMIT,
-               "band_prepare_u8: window area %d exceeds 1024", win_w * win_h);
+    SV_REQUIRE((int64_t)win_w * win_h <= 4096, SVAMD_ERR_LIMIT,
+               "band_prepare_u8: window area %d exceeds 4096", win_w * win_h);
     SV_REQUIRE((int64_t)(H + 1) * (W + 1) < (1LL << 31), SVAMD_ERR_LIMIT, "band_prepare_u8: image too large");
     SV_REQUIRE(workspace && (reinterpret_cast<uintptr_t>(workspace) & 255) == 0 &&
                    workspace_bytes >= svamd_band_scan_u8_workspace_bytes(H, W, win_w, win_h),
@@ -1184,9 +1184,15 @@ extern "C" int svamd_band_scan_u8(const uint8_t *left, const uint8_t *right, int
                "band_scan_u8: unknown mode %d", mode);
     SV_REQUIRE(stride_x == 1, SVAMD_ERR_LIMIT, "band_scan_u8: only stride_x == 1 is supported (got %d)",
                stride_x);
-    SV_REQUIRE((int64_t)win_w * win_h <= 1024, SVAMD_ERR_LIMIT,
-               "band_scan_u8: window area %d exceeds 1024 (float32 accumulation would not be exact)",
-               win_w * win_h);
+    // (the box-sum kernel adds integers: its bound is the tables', which a tile's LDS size keeps far away)
+    if (flags & SVAMD_BAND_BOX_SUMS)
+        SV_REQUIRE((int64_t)win_w * win_h <= 4096, SVAMD_ERR_LIMIT, "band_scan_u8: window area %d exceeds 4096",
+                   win_w * win_h);
+    else
+        SV_REQUIRE((int64_t)win_w * win_h <= 1024, SVAMD_ERR_LIMIT,
+                   "band_scan_u8: window area %d exceeds 1024 (float32 accumulation would not be exact; "
+                   "SVAMD_BAND_BOX_SUMS takes up to 4096)",
+                   win_w * win_h);
     SV_REQUIRE((int64_t)(H + 1) * (W + 1) < (1LL << 31), SVAMD_ERR_LIMIT, "band_scan_u8: image too large");
     SV_REQUIRE(workspace && (reinterpret_cast<uintptr_t>(workspace) & 255) == 0 &&
                    workspace_bytes >= svamd_band_scan_u8_workspace_bytes(H, W, win_w, win_h),

@@ -59,7 +59,8 @@ def test_argument_validation_needs_no_gpu():
     assert lib.svamd_band_box_sums_supported(31, 31, 1, 128) == 1
     assert lib.svamd_band_box_sums_supported(5, 200, 1, 6) == 0        # the tile's rows do not fit the LDS
     assert lib.svamd_band_box_sums_supported(31, 31, 1, 40000) == 0    # nor does a band this wide
-    assert lib.svamd_band_box_sums_supported(40, 40, 1, 8) == 0        # beyond the scan's window area
+    assert lib.svamd_band_box_sums_supported(40, 40, 1, 128) == 1      # larger windows than the multiply-add kernel takes
+    assert lib.svamd_band_box_sums_supported(80, 80, 1, 8) == 0        # beyond the tables' window area
 
 
 def test_host_modules_fail_loudly_without_gpu():

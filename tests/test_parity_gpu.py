@@ -934,6 +934,27 @@ def test_band_scan_box_sums_vs_oracle_and_products(mods, oracle, ww, wh, h, w, m
         assert np.array_equal(disp, pdisp) and np.array_equal(val, pval, equal_nan=True)
 
 
+@pytest.mark.parametrize('ww,wh,h,w,md,stride', [(40, 40, 70, 330, 20, 1), (45, 44, 60, 300, 128, 1),
+                                                 (60, 40, 80, 280, 12, 2), (50, 50, 75, 310, 9, 1), (128, 32, 40, 400, 7, 1)])
+def test_band_scan_box_sums_large_windows(mods, oracle, ww, wh, h, w, md, stride):
+    """Windows beyond the multiply-add kernel's 1024 pixels (its float32 sums would not be
+    exact) run by box sums, whose integer sums are: the shipped configurations' 40 x 40 and
+    50 x 50 windows among them.  Score volume, disparities and selection against the oracle."""
+    left, right = synthetic_pair(h, w, ww + wh + md, min(md, 12))
+    b = mods['b']
+    with pytest.raises(mods['n'].NativeError, match='exceeds 1024'):
+        b.band_scan(left, right, ww, wh, md, row_stride=stride)
+    disp, val, scores = b.band_scan(left, right, ww, wh, md, row_stride=stride, want_scores=True, method='sums')
+    odisp, oval, oscores = oracle.band_scan(left, right, ww, wh, md, stride_y=stride, want_scores=True)
+    assert_surface_close(scores, oscores, 1e-12, 'box-sum band scores, large window')
+    assert np.array_equal(disp, odisp)
+    assert_surface_close(val, oval, 1e-12, 'box-sum band values, large window')
+    disp, val = b.band_scan(left, right, ww, wh, md, correlation_threshold=0.5, row_stride=stride, method='sums')
+    odisp, oval = oracle.band_scan(left, right, ww, wh, md, stride_y=stride, mode='fold', threshold=0.5)
+    assert np.array_equal(disp, odisp)
+    assert_surface_close(val, oval, 1e-12, 'box-sum band fold values, large window')
+
+
 def test_band_scan_takes_the_loaders_output(mods):
     '''`downsample(image, 1)` scales 8-bit levels by the product with 1 / 255 (not the
     quotient by 255); the band scan recognises both and scans the same integers.'''
@@ -1062,6 +1083,8 @@ def test_band_scan_rejects_unsupported(mods):
         b.band_scan(np.zeros((40, 40), dtype=complex), np.zeros((40, 40)), 7, 7, 3)
     with pytest.raises(mods['n'].NativeError, match='exceeds 1024'):
         b.band_scan(np.zeros((80, 80), np.uint8), np.zeros((80, 80), np.uint8), 33, 32, 3)
+    with pytest.raises(mods['n'].NativeError, match='exceeds 4096'):
+        b.band_scan(np.zeros((80, 80), np.uint8), np.zeros((80, 80), np.uint8), 70, 64, 3, method='sums')
     with pytest.raises(mods['n'].NativeError, match='does not fit the LDS tile'):
         b.band_scan(np.zeros((230, 280), np.uint8), np.zeros((230, 280), np.uint8), 5, 200, 6)
     # the box-sum kernel keeps a tile's table and the right band under all offsets in LDS
