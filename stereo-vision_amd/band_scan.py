@@ -145,12 +145,20 @@ class BandScanner:
 
 
 def band_scan(left_image, right_image, window_width, window_height, max_disparity,
-              correlation_threshold=None, row_stride=1, want_scores=False, method='products'):
+              correlation_threshold=None, row_stride=1, want_scores=False, method='products', column_stride=1):
     '''Scans every window_width x window_height window of the left image against
     the right image at horizontal offsets -max_disparity..+max_disparity.
     Returns (disparity int32 [rows, cols], correlation float64 [rows, cols]) and,
     if asked, the full score volume [rows, cols, 2*max_disparity+1] (NaN where a
-    candidate box leaves the image or a window is constant).'''
+    candidate box leaves the image or a window is constant).  column_stride > 1 keeps the
+    windows at every column_stride-th column: the kernels scan every column (their
+    neighbouring windows share their work) and the others are dropped here.'''
+    if int(column_stride) < 1:
+        raise ValueError('column_stride must be a positive integer')
+    if int(column_stride) > 1:
+        out = band_scan(left_image, right_image, window_width, window_height, max_disparity,
+                        correlation_threshold, row_stride, want_scores, method)
+        return tuple(np.ascontiguousarray(a[:, ::int(column_stride)]) for a in out)
     left, right = np.asarray(left_image), np.asarray(right_image)
     if left.shape != right.shape:
         raise Exception('Dimensions of template and region images must match')

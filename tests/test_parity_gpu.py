@@ -955,6 +955,25 @@ def test_band_scan_box_sums_large_windows(mods, oracle, ww, wh, h, w, md, stride
     assert_surface_close(val, oval, 1e-12, 'box-sum band fold values, large window')
 
 
+@pytest.mark.parametrize('method', ['products', 'sums'])
+def test_band_scan_column_stride(mods, oracle, method):
+    """Windows at every third column and every second row (a window_overlap below the dense
+    0.96): the same windows, offsets and selections as the oracle's strided scan."""
+    left, right = synthetic_pair(60, 200, 33, 6)
+    b = mods['b']
+    disp, val, scores = b.band_scan(left, right, 15, 15, 9, row_stride=2, column_stride=3, want_scores=True,
+                                    method=method)
+    odisp, oval, oscores = oracle.band_scan(left, right, 15, 15, 9, stride_x=3, stride_y=2, want_scores=True)
+    assert disp.shape == odisp.shape and np.array_equal(disp, odisp)
+    assert_surface_close(scores, oscores, 1e-12, 'strided band scores')
+    assert_surface_close(val, oval, 1e-12, 'strided band values')
+    disp, val = b.band_scan(left, right, 15, 15, 9, correlation_threshold=0.5, row_stride=2, column_stride=3,
+                            method=method)
+    odisp, oval = oracle.band_scan(left, right, 15, 15, 9, stride_x=3, stride_y=2, mode='fold', threshold=0.5)
+    assert np.array_equal(disp, odisp)
+    assert_surface_close(val, oval, 1e-12, 'strided band fold values')
+
+
 def test_band_scan_takes_the_loaders_output(mods):
     '''`downsample(image, 1)` scales 8-bit levels by the product with 1 / 255 (not the
     quotient by 255); the band scan recognises both and scans the same integers.'''
